@@ -1,0 +1,258 @@
+/*
+ * rt_hip.h - C ABI of the MI355X (gfx950) frame renderer.
+ *
+ * The library replaces lib_raytracer's per-frame render path: the pixel loop of
+ * native_app/src/main.rs:46-66 together with everything it calls in
+ * lib_raytracer/src/raytracing/raytracer.rs, raytracing/intersect.rs and
+ * scene.rs:120-140.  The shape of the interface follows the reference's one
+ * frame-level renderer, GpuRenderer (web_app/wasm/src/gpu_renderer.rs:44-68,
+ * 280, 356-364): the scene is uploaded once, the camera is rewritten per frame,
+ * and `render` fills a caller-owned 8-bit canvas whose row 0 is the top row.
+ *
+ * All scene inputs are plain arrays of the structs below.  They mirror the
+ * public fields of lib_raytracer::Scene (scene.rs:6-20) one to one; material
+ * and mesh references are the indices the reference's parser has already
+ * resolved (scene_file/parser.rs:124-144).  Matrices are column-major, 16
+ * floats, exactly as nalgebra stores a glm::Mat4.
+ *
+ * Conventions: every input pointer is borrowed for the duration of the call;
+ * outputs are caller-allocated; functions return RT_OK (0) or a negative
+ * RtStatus and never unwind; a handle must be driven by one thread at a time.
+ * The text of the last error of the calling thread is available from
+ * rt_last_error().
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum RtStatus {
+    RT_OK = 0,
+    RT_ERR_INVALID_ARGUMENT = -1,
+    RT_ERR_OUT_OF_RANGE = -2,   /* an index in the scene points outside its array */
+    RT_ERR_BVH_TOO_DEEP = -3,   /* traversal would need more than RT_BVH_STACK_LEN entries */
+    RT_ERR_DEVICE = -4,         /* a HIP call failed */
+    RT_ERR_NO_DEVICE = -5,
+    RT_ERR_IO = -6,
+    RT_ERR_PARSE = -7
+} RtStatus;
+
+/* raytracing/material.rs:18-25; numbering as gpu_types.rs:196-201 */
+enum { RT_MATERIAL_PHONG = 0, RT_MATERIAL_REFLECT_AND_PHONG = 1, RT_MATERIAL_REFLECT_AND_REFRACT = 2 };
+/* raytracing/background.rs:3-7; numbering as gpu_types.rs:32-45 */
+enum { RT_BACKGROUND_SOLID_COLOR = 0, RT_BACKGROUND_COLORED_DIRECTION = 1 };
+
+/* intersect.rs:240 - the reference's traversal stack holds 32 node indices and panics beyond. */
+#define RT_BVH_STACK_LEN 32
+/* bvh/node.rs:22 */
+#define RT_LEAF_TRIANGLES 5
+/* raytracer.rs:9 */
+#define RT_DEFAULT_MAX_DEPTH 10
+
+/* raytracing/light.rs:4-13.  position.w == 0 marks a directional light. */
+typedef struct RtLight {
+    float position[4];
+    float ambient[3];
+    float diffuse[3];
+    float specular[3];
+} RtLight;
+
+/* raytracing/material.rs:6-16 */
+typedef struct RtMaterial {
+    float emissive[3];
+    float ambient[3];
+    float diffuse[3];
+    float specular[3];
+    float shininess;
+    uint32_t material_type;   /* RT_MATERIAL_* */
+    float index_inner;        /* only for RT_MATERIAL_REFLECT_AND_REFRACT */
+    float index_outer;
+} RtMaterial;
+
+/* geometry/plane.rs:6-12; `normal` is already normalised by Plane::new */
+typedef struct RtPlane {
+    float normal[3];
+    float distance;
+    uint32_t material;
+} RtPlane;
+
+/* geometry/sphere.rs:4-9 */
+typedef struct RtSphere {
+    float center[3];
+    float radius;
+    uint32_t material;
+} RtSphere;
+
+/* geometry/triangle.rs:6-12; used both for Scene::triangles and Scene::mesh_triangles */
+typedef struct RtTriangle {
+    float vertices[3][3];
+    float normals[3][3];
+    float face_normal[3];     /* Triangle::normal(), precomputed by Triangle::new */
+    uint32_t material;
+} RtTriangle;
+
+/* bvh/node.rs:6-19 + geometry/aabb.rs:3-6.  Child and triangle indices are absolute
+ * indices into RtSceneDesc::mesh_bvh_nodes / mesh_triangles, as in the reference. */
+typedef struct RtBvhNode {
+    float aabb_min[3];
+    float aabb_max[3];
+    uint32_t is_leaf;
+    uint32_t child_left;
+    uint32_t child_right;
+    uint32_t triangle_count;                       /* <= RT_LEAF_TRIANGLES */
+    uint32_t triangle_indices[RT_LEAF_TRIANGLES];
+} RtBvhNode;
+
+/* geometry/mesh.rs:8-12 + bvh/mod.rs:12-15; ranges are half-open [begin, end) */
+typedef struct RtMesh {
+    uint32_t triangle_begin;
+    uint32_t triangle_end;
+    uint32_t node_begin;      /* the root is node_begin (intersect.rs:243) */
+    uint32_t node_end;
+    uint32_t max_depth;
+} RtMesh;
+
+/* raytracing/instance.rs:6-14 */
+typedef struct RtMeshInstance {
+    float rotation_scale[16];
+    float rotation_scale_inverse[16];
+    float model[16];
+    float model_inverse[16];
+    uint32_t mesh;
+    int32_t material_override;    /* -1 = None */
+} RtMeshInstance;
+
+typedef struct RtBackground {
+    uint32_t type;                /* RT_BACKGROUND_* */
+    float color[3];               /* only for RT_BACKGROUND_SOLID_COLOR */
+} RtBackground;
+
+/* The arrays of lib_raytracer::Scene (scene.rs:6-20), borrowed. */
+typedef struct RtSceneDesc {
+    RtBackground background;
+    uint32_t n_lights;
+    uint32_t n_materials;
+    uint32_t n_planes;
+    uint32_t n_spheres;
+    uint32_t n_triangles;
+    uint32_t n_mesh_triangles;
+    uint32_t n_mesh_bvh_nodes;
+    uint32_t n_meshes;
+    uint32_t n_mesh_instances;
+    const RtLight* lights;
+    const RtMaterial* materials;
+    const RtPlane* planes;
+    const RtSphere* spheres;
+    const RtTriangle* triangles;
+    const RtTriangle* mesh_triangles;
+    const RtBvhNode* mesh_bvh_nodes;
+    const RtMesh* meshes;
+    const RtMeshInstance* mesh_instances;
+} RtSceneDesc;
+
+/* Per-pixel primary-hit record and frame-wide ray statistics (optional outputs). */
+
+/* prim_id = kind << 30 | index.  For RT_PRIM_MESH_TRIANGLE the index is the absolute
+ * index into mesh_triangles and instance_id names the Scene::mesh_instances entry. */
+enum { RT_PRIM_PLANE = 0, RT_PRIM_SPHERE = 1, RT_PRIM_TRIANGLE = 2, RT_PRIM_MESH_TRIANGLE = 3 };
+#define RT_PRIM_NONE 0xFFFFFFFFu
+#define RT_INSTANCE_NONE 0xFFFFFFFFu
+
+/* bits of RtAux::flags, all about the primary ray of the pixel */
+#define RT_FLAG_HIT            0x01u  /* Scene::intersect returned Some */
+#define RT_FLAG_FRONTSIDE      0x02u  /* Hitpoint::on_frontside */
+#define RT_FLAG_REFLECTION_HIT 0x04u  /* the reflected child ray (raytracer.rs:91,109) hit geometry */
+#define RT_FLAG_REFRACTION_HIT 0x08u  /* the transmitted child ray (raytracer.rs:111) hit geometry */
+#define RT_FLAG_SHADOW_LIGHT0  0x10u  /* trace_shadow_ray (raytracer.rs:78) said "shadow" for light i: bit 4+i, i < 4 */
+
+enum {
+    RT_CTR_RAYS = 0,          /* calls of Scene::intersect = primary + shadow + reflected + transmitted */
+    RT_CTR_PRIMARY,
+    RT_CTR_SHADOW,
+    RT_CTR_REFLECTED,
+    RT_CTR_TRANSMITTED,
+    RT_CTR_AABB_TESTS,        /* AABB::intersect calls of the reference's un-pruned traversal */
+    RT_CTR_MESH_TRIANGLE_TESTS,
+    RT_CTR_TRIANGLE_TESTS,    /* Scene::triangles */
+    RT_CTR_SPHERE_TESTS,
+    RT_CTR_PLANE_TESTS,
+    RT_CTR_INSTANCE_TRANSFORMS,
+    RT_CTR_MESH_HITS,         /* instance traversals that returned a hit (normals fetched) */
+    RT_CTR_LIGHT_SHADES,      /* Raytracer::radiance calls */
+    RT_N_COUNTERS
+};
+
+typedef struct RtAux {
+    uint32_t* prim_id;        /* W*H, row 0 = top, or NULL */
+    uint32_t* instance_id;    /* W*H or NULL */
+    uint8_t* flags;           /* W*H or NULL */
+    uint64_t counters[RT_N_COUNTERS];   /* the device path fills RT_CTR_RAYS..RT_CTR_TRANSMITTED, the rest stay 0 */
+} RtAux;
+
+enum { RT_FORMAT_RGB8 = 0, RT_FORMAT_RGBA8 = 1 };
+
+/* Frame tiles are RT_TILE_DIM x RT_TILE_DIM pixels, numbered row-major over the tile grid
+ * (ceil(W/RT_TILE_DIM) columns).  Shard s of n renders the tiles t with t % n == s - the
+ * row interlacing of web_app/wasm/src/renderer.rs:68-76, in two dimensions. */
+#define RT_TILE_DIM 32
+
+typedef struct RtRenderParams {
+    uint32_t max_depth;       /* MAX_RAY_RECURSION_DEPTH, raytracer.rs:9; 0 means RT_DEFAULT_MAX_DEPTH */
+    uint32_t output_format;   /* RT_FORMAT_* ; RGBA8 sets alpha = 255 as web_app/wasm/src/color.rs:10-21 */
+    uint32_t shard_index;     /* which tiles to render: see RT_TILE_DIM */
+    uint32_t shard_count;     /* 0 or 1 = the whole frame */
+    void* stream;             /* hipStream_t to enqueue on; NULL = the handle's own stream */
+} RtRenderParams;
+
+typedef struct RtScene RtScene;
+
+/* Replaces GpuRenderer::new / setup_pipeline_and_buffers (gpu_renderer.rs:70-246): validates the
+ * scene, copies it into device-resident arrays on HIP device `device_id`.  The camera is unset. */
+int rt_scene_create(const RtSceneDesc* desc, int device_id, RtScene** out_scene);
+
+/* Replaces the per-frame camera-uniform write (gpu_renderer.rs:321-322).  `screen_to_world` is
+ * Scene::screen_to_world() (scene.rs:50-52), column-major; width/height are camera.screen_dimensions. */
+int rt_scene_set_camera(RtScene* scene, const float screen_to_world[16], uint32_t width, uint32_t height);
+
+/* Replaces paint_scene (native_app/src/main.rs:46-66) and GpuRenderer::render (gpu_renderer.rs:280-354):
+ * renders the whole frame (shard fields of `params` are ignored) and copies it to `out_pixels`
+ * (host memory, W*H*3 or W*H*4 bytes, row 0 = top as canvas.rs:35-46).  `aux` may be NULL; its
+ * non-NULL arrays are host memory.  Synchronous. */
+int rt_render(RtScene* scene, const RtRenderParams* params, uint8_t* out_pixels, RtAux* aux);
+
+/* Same frame, output left in device memory and the call asynchronous on params->stream.
+ * shard_count <= 1: `d_out` receives the row-major frame.  shard_count > 1: `d_out` receives only
+ * this shard's tiles, tile-major: local tile k (global tile shard_index + k*shard_count) occupies
+ * bytes [k*T, (k+1)*T), T = RT_TILE_DIM*RT_TILE_DIM*bytes_per_pixel, pixels row-major inside the
+ * tile; pixels outside the frame are zero.  Use rt_shard_bytes for the buffer size. */
+int rt_render_device(RtScene* scene, const RtRenderParams* params, void* d_out);
+
+/* Bytes one shard writes in rt_render_device (equal for every shard_index: the tile count is
+ * rounded up to a multiple of shard_count so that gathers are uniform). */
+int rt_shard_bytes(const RtScene* scene, const RtRenderParams* params, uint64_t* out_bytes);
+
+/* After an all-gather of the shard buffers (rank-major, rt_shard_bytes each) writes the row-major
+ * frame to `d_frame`.  Stitches rows as web_app/src/main/model.ts:115-129 stitches worker rows. */
+int rt_assemble_shards(RtScene* scene, const RtRenderParams* params, const void* d_gathered, void* d_frame);
+
+/* Ray counts of the last rt_render / rt_render_device on this handle (waits for it to finish).
+ * Fills RT_CTR_RAYS..RT_CTR_TRANSMITTED. */
+int rt_last_ray_counts(RtScene* scene, uint64_t counters[RT_N_COUNTERS]);
+
+/* Time of the last rt_render / rt_render_device on this handle between its first and last
+ * enqueued command, measured with HIP events on the stream the kernels ran on. */
+int rt_last_render_ms(RtScene* scene, float* out_ms);
+
+void rt_scene_destroy(RtScene* scene);
+
+/* Thread-local, static storage; never NULL. */
+const char* rt_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_HIP_H */

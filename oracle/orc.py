@@ -1,0 +1,230 @@
+"""TEST INFRASTRUCTURE - ctypes wrapper of the CPU oracle (oracle/liborc.so).
+
+Only tests/, __graft_entry__.smoke() and the cpu_baseline leg of bench.py may import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(_HERE))
+from rust_raytracer_amd import abi  # noqa: E402  (struct layouts of include/rt_hip.h)
+
+_LIB = None
+
+
+def build(force: bool = False) -> str:
+    """Compile liborc.so with the Makefile next to this file if it is missing or stale."""
+    so = os.path.join(_HERE, "liborc.so")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".cpp", ".h"))]
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "rt_hip.h"))
+    stale = force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
+    if stale:
+        subprocess.run(["make", "-C", _HERE, "-B", "liborc.so"], check=True, capture_output=True)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liborc.so")
+        if not os.path.exists(so):
+            build()
+        L = C.CDLL(so)
+        L.orc_last_error.restype = C.c_char_p
+        for name in ("orc_scene_load_text", "orc_scene_load_file"):
+            getattr(L, name).restype = C.c_void_p
+            getattr(L, name).argtypes = [C.c_char_p, C.c_char_p]
+        L.orc_scene_from_desc.restype = C.c_void_p
+        L.orc_scene_from_desc.argtypes = [C.POINTER(abi.RtSceneDesc), C.POINTER(C.c_float), C.c_uint32, C.c_uint32]
+        L.orc_scene_free.argtypes = [C.c_void_p]
+        L.orc_scene_resize.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        L.orc_scene_turn_camera.argtypes = [C.c_void_p] + [C.c_float] * 4
+        L.orc_scene_set_camera_matrix.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.c_uint32]
+        L.orc_scene_camera.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
+        L.orc_scene_desc.argtypes = [C.c_void_p, C.POINTER(abi.RtSceneDesc)]
+        L.orc_render.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_int,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_trace_pixel.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_uint32, C.POINTER(C.c_float),
+                                      C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)]
+        fp = C.POINTER(C.c_float)
+        L.orc_kat_sphere.argtypes = [fp, C.c_float, fp, fp, fp]
+        L.orc_kat_plane.argtypes = [fp, C.c_float, fp, fp, fp]
+        L.orc_kat_triangle.argtypes = [fp, fp, fp, fp, fp]
+        L.orc_kat_aabb.argtypes = [fp, fp, fp, fp]
+        L.orc_hull.argtypes = [fp, C.c_uint32, fp]
+        L.orc_aabb_surface_area.argtypes = [fp, fp]
+        L.orc_aabb_surface_area.restype = C.c_float
+        L.orc_mat_inverse.argtypes = [fp, fp]
+        L.orc_mat_mul.argtypes = [fp, fp, fp]
+        L.orc_make_instance.argtypes = [C.c_uint32, fp, fp, fp, C.c_int32, C.POINTER(abi.RtMeshInstance)]
+        L.orc_screen_to_world.argtypes = [fp, C.c_uint32, C.c_uint32, fp]
+        L.orc_build_mesh.argtypes = [C.c_char_p, C.c_int, C.c_uint32, C.POINTER(abi.RtTriangle), C.c_uint32,
+                                     C.POINTER(abi.RtBvhNode), C.c_uint32, C.POINTER(abi.RtMesh)]
+        _LIB = L
+    return _LIB
+
+
+def _f(values):
+    arr = (C.c_float * len(values))(*[float(v) for v in values])
+    return arr
+
+
+class OracleScene:
+    """A lib_raytracer::Scene as the oracle holds it."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise RuntimeError("oracle: " + lib().orc_last_error().decode())
+        self._h = handle
+
+    @classmethod
+    def from_file(cls, json_path: str, model_dir: str = ""):
+        return cls(lib().orc_scene_load_file(json_path.encode(), model_dir.encode()))
+
+    @classmethod
+    def from_text(cls, json_text: str, model_dir: str = ""):
+        return cls(lib().orc_scene_load_text(json_text.encode(), model_dir.encode()))
+
+    @classmethod
+    def from_desc(cls, desc: abi.RtSceneDesc, screen_to_world, width: int, height: int):
+        m = _f(np.asarray(screen_to_world, dtype=np.float32).reshape(16))
+        return cls(lib().orc_scene_from_desc(C.byref(desc), m, width, height))
+
+    def close(self):
+        if self._h:
+            lib().orc_scene_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def resize(self, width: int, height: int):
+        lib().orc_scene_resize(self._h, width, height)
+
+    def turn_camera(self, bx, by, ex, ey):
+        lib().orc_scene_turn_camera(self._h, bx, by, ex, ey)
+
+    def set_camera_matrix(self, m, width, height):
+        lib().orc_scene_set_camera_matrix(self._h, _f(np.asarray(m, dtype=np.float32).reshape(16)), width, height)
+
+    def camera(self):
+        m = (C.c_float * 16)()
+        d = (C.c_uint32 * 2)()
+        lib().orc_scene_camera(self._h, m, d)
+        return np.array(m, dtype=np.float32), int(d[0]), int(d[1])
+
+    def desc(self) -> abi.RtSceneDesc:
+        """Borrowed view of the scene arrays (valid while this object lives)."""
+        d = abi.RtSceneDesc()
+        lib().orc_scene_desc(self._h, C.byref(d))
+        return d
+
+    def render(self, max_depth: int = 10, threads: int = 0, rows=None, channels: int = 3, aux: bool = True):
+        """Returns dict(rgb[H,W,channels] u8, prim_id[H,W] u32, instance_id[H,W] u32, flags[H,W] u8,
+        counters[RT_N_COUNTERS] u64).  Rows outside `rows` stay zero."""
+        _, w, h = self.camera()
+        threads = threads or (os.cpu_count() or 1)
+        r0, r1 = rows if rows is not None else (0, h)
+        rgb = np.zeros((h, w, channels), dtype=np.uint8)
+        prim = np.full((h, w), 0, dtype=np.uint32) if aux else None
+        inst = np.full((h, w), 0, dtype=np.uint32) if aux else None
+        flags = np.zeros((h, w), dtype=np.uint8) if aux else None
+        ctr = np.zeros(abi.RT_N_COUNTERS, dtype=np.uint64)
+        ptr = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
+        rc = lib().orc_render(self._h, max_depth, threads, r0, r1, channels, ptr(rgb), ptr(prim), ptr(inst),
+                              ptr(flags), ptr(ctr))
+        if rc != 0:
+            raise RuntimeError("oracle: " + lib().orc_last_error().decode())
+        return {"rgb": rgb, "prim_id": prim, "instance_id": inst, "flags": flags, "counters": ctr}
+
+    def trace_pixel(self, x: float, y: float, max_depth: int = 10):
+        col = (C.c_float * 3)()
+        ids = (C.c_uint32 * 2)()
+        fl = C.c_uint8()
+        rc = lib().orc_trace_pixel(self._h, x, y, max_depth, col, ids, C.byref(fl))
+        if rc != 0:
+            raise RuntimeError("oracle: " + lib().orc_last_error().decode())
+        return np.array(col, dtype=np.float32), int(ids[0]), int(ids[1]), int(fl.value)
+
+
+def kat_sphere(center, radius, origin, direction):
+    t = C.c_float()
+    hit = lib().orc_kat_sphere(_f(center), radius, _f(origin), _f(direction), C.byref(t))
+    return t.value if hit else None
+
+
+def kat_plane(normal, distance, origin, direction):
+    t = C.c_float()
+    hit = lib().orc_kat_plane(_f(normal), distance, _f(origin), _f(direction), C.byref(t))
+    return t.value if hit else None
+
+
+def kat_triangle(vertices, normals, origin, direction):
+    t = C.c_float()
+    hit = lib().orc_kat_triangle(_f(np.ravel(vertices)), _f(np.ravel(normals)), _f(origin), _f(direction), C.byref(t))
+    return t.value if hit else None
+
+
+def kat_aabb(bmin, bmax, origin, direction) -> bool:
+    return bool(lib().orc_kat_aabb(_f(bmin), _f(bmax), _f(origin), _f(direction)))
+
+
+def hull(vertices):
+    v = np.asarray(vertices, dtype=np.float32).reshape(-1, 3)
+    out = (C.c_float * 6)()
+    ok = lib().orc_hull(_f(v.ravel()) if len(v) else (C.c_float * 1)(), len(v), out)
+    return (np.array(out[:3], dtype=np.float32), np.array(out[3:], dtype=np.float32)) if ok else None
+
+
+def aabb_surface_area(bmin, bmax) -> float:
+    return float(lib().orc_aabb_surface_area(_f(bmin), _f(bmax)))
+
+
+def mat_inverse(m):
+    out = (C.c_float * 16)()
+    lib().orc_mat_inverse(_f(np.asarray(m, dtype=np.float32).reshape(16)), out)
+    return np.array(out, dtype=np.float32)
+
+
+def mat_mul(a, b):
+    out = (C.c_float * 16)()
+    lib().orc_mat_mul(_f(np.asarray(a, dtype=np.float32).reshape(16)), _f(np.asarray(b, dtype=np.float32).reshape(16)), out)
+    return np.array(out, dtype=np.float32)
+
+
+def screen_to_world(position, orientation_radians, y_fov_degrees, z_near, z_far, width, height):
+    out = (C.c_float * 16)()
+    lib().orc_screen_to_world(_f(list(position) + list(orientation_radians) + [y_fov_degrees, z_near, z_far]),
+                              width, height, out)
+    return np.array(out, dtype=np.float32)
+
+
+def make_instance(mesh, position, orientation_radians, scale, material_override=-1) -> abi.RtMeshInstance:
+    out = abi.RtMeshInstance()
+    lib().orc_make_instance(mesh, _f(position), _f(orientation_radians), _f(scale), material_override, C.byref(out))
+    return out
+
+
+def build_mesh(obj_text: str, counter_clockwise: bool = True, material: int = 0):
+    """(triangles bytes, nodes bytes, RtMesh) of one OBJ loaded the reference's way."""
+    mesh = abi.RtMesh()
+    rc = lib().orc_build_mesh(obj_text.encode(), int(counter_clockwise), material, None, 0, None, 0, C.byref(mesh))
+    if rc != 0:
+        raise RuntimeError("oracle: " + lib().orc_last_error().decode())
+    nt = mesh.triangle_end - mesh.triangle_begin
+    nn = mesh.node_end - mesh.node_begin
+    tris = (abi.RtTriangle * nt)()
+    nodes = (abi.RtBvhNode * nn)()
+    rc = lib().orc_build_mesh(obj_text.encode(), int(counter_clockwise), material, tris, nt, nodes, nn, C.byref(mesh))
+    if rc != 0:
+        raise RuntimeError("oracle: " + lib().orc_last_error().decode())
+    return bytes(tris), bytes(nodes), mesh
