@@ -249,6 +249,12 @@ int rt_last_render_ms(RtScene* scene, float* out_ms);
 
 void rt_scene_destroy(RtScene* scene);
 
+/* Test aids.  The first caps the per-depth ray queue at `capacity` rays (0 = the default, four rays
+ * per pixel): children that do not fit are traced by the lane that produced them, with the same
+ * result.  The second reports how many children took that route in the last frame. */
+int rt_debug_set_queue_capacity(RtScene* scene, uint32_t capacity);
+int rt_debug_last_spilled(RtScene* scene, uint32_t* out_count);
+
 /* Thread-local, static storage; never NULL. */
 const char* rt_last_error(void);
 

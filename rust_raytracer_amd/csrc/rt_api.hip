@@ -1,0 +1,503 @@
+// Host side of the C ABI declared in include/rt_hip.h: scene validation and upload, per-frame
+// buffers, kernel sequencing.  No rendering arithmetic happens here - if the device code cannot
+// run, every entry point fails with RT_ERR_DEVICE / RT_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rt_device.h"
+
+extern "C" {
+hipError_t rt_launch_trace_level(const DScene* S, const DFrame* F, uint32_t level, uint32_t blocks, hipStream_t stream);
+hipError_t rt_launch_next_level(DCounters* C, uint32_t next_level, hipStream_t stream);
+hipError_t rt_launch_resolve(const DFrame* F, uint8_t* out, uint32_t bytes_per_pixel, uint32_t tiled, hipStream_t stream);
+hipError_t rt_launch_resolve_aux(const DFrame* F, uint32_t* prim, uint32_t* inst, uint8_t* flags, hipStream_t stream);
+hipError_t rt_launch_assemble(const uint8_t* gathered, uint8_t* frame, uint32_t width, uint32_t height, uint32_t tiles_x,
+                              uint32_t shard_count, uint32_t tiles_per_shard, uint32_t bytes_per_pixel, hipStream_t stream);
+int rt_query_trace_blocks_per_cu(uint32_t stack_entries);
+}
+
+static thread_local char g_error[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof(g_error), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return fail(RT_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+struct RtScene {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool timed = false;
+    hipStream_t last_stream = nullptr;
+    int n_cus = 0;
+    int blocks_per_cu = 1;
+    std::vector<void*> scene_allocs;
+    DScene d{};
+    bool camera_set = false;
+    float screen_to_world[16] = {};
+    uint32_t width = 0, height = 0;
+    // per-frame buffers, reallocated when the key below changes
+    struct FrameKey { uint32_t w = 0, h = 0, shard_count = 0, max_depth = 0, aux = 0, blocks = 0, capacity = 0; } key;
+    DFrame f{};
+    std::vector<void*> frame_allocs;
+    uint8_t* d_pixels = nullptr;        // staging for rt_render
+    size_t d_pixels_bytes = 0;
+    uint32_t *d_aux_prim_out = nullptr, *d_aux_inst_out = nullptr;
+    uint8_t* d_aux_flags_out = nullptr;
+    size_t aux_out_pixels = 0;
+    uint32_t debug_queue_capacity = 0;
+};
+
+template <class T>
+static int upload(RtScene* s, const std::vector<T>& host, const T** out) {
+    *out = nullptr;
+    if (host.empty()) return RT_OK;
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, host.size() * sizeof(T)));
+    s->scene_allocs.push_back(p);
+    HIP_TRY(hipMemcpy(p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = static_cast<const T*>(p);
+    return RT_OK;
+}
+
+static void mat34(const float* colmajor, DMat34* out) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 4; ++j) out->r[i][j] = colmajor[4 * j + i];
+}
+
+static float4 f4(float x, float y, float z, float w) { float4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+static float bits(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+namespace {
+// Re-lays one mesh's BVH out in the order the reference visits it (pop, push left, push right:
+// intersect.rs:245-256, i.e. right-first pre-order) with the triangles of a leaf made consecutive.
+struct MeshLayout {
+    uint32_t root = 0xFFFFFFFFu;
+    uint32_t stack_need = 1;
+};
+}  // namespace
+
+static int layout_mesh(const RtSceneDesc* desc, uint32_t mesh_index, std::vector<float4>& nodes, std::vector<float4>& hot,
+                       std::vector<float4>& cold, MeshLayout* out) {
+    const RtMesh& m = desc->meshes[mesh_index];
+    if (m.node_begin > m.node_end || m.node_end > desc->n_mesh_bvh_nodes)
+        return fail(RT_ERR_OUT_OF_RANGE, "mesh %u: node range [%u, %u) outside the %u nodes", mesh_index, m.node_begin,
+                    m.node_end, desc->n_mesh_bvh_nodes);
+    if (m.node_begin == m.node_end) return RT_OK;            // empty BVH: never hit (intersect.rs:235-237)
+    struct Item { uint32_t src; uint32_t parent_slot; bool right; };
+    std::vector<Item> stack;
+    stack.push_back({m.node_begin, 0xFFFFFFFFu, false});
+    size_t visited = 0, max_sp = 1;
+    const size_t budget = 4 * (size_t)(m.node_end - m.node_begin) + 16;
+    while (!stack.empty()) {
+        Item it = stack.back();
+        stack.pop_back();
+        if (it.src >= desc->n_mesh_bvh_nodes)
+            return fail(RT_ERR_OUT_OF_RANGE, "mesh %u: BVH node index %u outside the %u nodes", mesh_index, it.src,
+                        desc->n_mesh_bvh_nodes);
+        if (++visited > budget) return fail(RT_ERR_INVALID_ARGUMENT, "mesh %u: BVH is not a tree", mesh_index);
+        const RtBvhNode& n = desc->mesh_bvh_nodes[it.src];
+        uint32_t dev = (uint32_t)(nodes.size() / 2);
+        if (it.parent_slot == 0xFFFFFFFFu) out->root = dev;
+        else {
+            float4& p = nodes[2 * (size_t)it.parent_slot + (it.right ? 1 : 0)];
+            p.w = bits(dev);
+        }
+        if (n.is_leaf) {
+            if (n.triangle_count > RT_LEAF_TRIANGLES)
+                return fail(RT_ERR_INVALID_ARGUMENT, "mesh %u: leaf with %u triangles", mesh_index, n.triangle_count);
+            uint32_t first = (uint32_t)(hot.size() / 3);
+            for (uint32_t k = 0; k < n.triangle_count; ++k) {
+                uint32_t ti = n.triangle_indices[k];
+                if (ti >= desc->n_mesh_triangles)
+                    return fail(RT_ERR_OUT_OF_RANGE, "mesh %u: triangle index %u outside the %u mesh triangles", mesh_index, ti,
+                                desc->n_mesh_triangles);
+                const RtTriangle& t = desc->mesh_triangles[ti];
+                if (t.material >= desc->n_materials)
+                    return fail(RT_ERR_OUT_OF_RANGE, "mesh triangle %u: material %u outside the %u materials", ti, t.material,
+                                desc->n_materials);
+                const float* p0 = t.vertices[0];
+                // e1 = p1 - p0, e2 = p2 - p0: the first two operations of Triangle::intersect (intersect.rs:147-148)
+                float e1[3], e2[3];
+                for (int c = 0; c < 3; ++c) { e1[c] = t.vertices[1][c] - p0[c]; e2[c] = t.vertices[2][c] - p0[c]; }
+                hot.push_back(f4(p0[0], p0[1], p0[2], e1[0]));
+                hot.push_back(f4(e1[1], e1[2], e2[0], e2[1]));
+                hot.push_back(f4(e2[2], t.face_normal[0], t.face_normal[1], t.face_normal[2]));
+                cold.push_back(f4(t.normals[0][0], t.normals[0][1], t.normals[0][2], bits(ti)));
+                cold.push_back(f4(t.normals[1][0], t.normals[1][1], t.normals[1][2], bits(t.material)));
+                cold.push_back(f4(t.normals[2][0], t.normals[2][1], t.normals[2][2], 0.0f));
+            }
+            nodes.push_back(f4(n.aabb_min[0], n.aabb_min[1], n.aabb_min[2], bits(first)));
+            nodes.push_back(f4(n.aabb_max[0], n.aabb_max[1], n.aabb_max[2], bits(RT_NODE_LEAF_BIT | n.triangle_count)));
+        } else {
+            nodes.push_back(f4(n.aabb_min[0], n.aabb_min[1], n.aabb_min[2], bits(0xFFFFFFFFu)));
+            nodes.push_back(f4(n.aabb_max[0], n.aabb_max[1], n.aabb_max[2], bits(0xFFFFFFFFu)));
+            stack.push_back({n.child_left, dev, false});
+            stack.push_back({n.child_right, dev, true});
+            if (stack.size() > max_sp) max_sp = stack.size();
+        }
+    }
+    out->stack_need = (uint32_t)max_sp;
+    return RT_OK;
+}
+
+extern "C" int rt_scene_create(const RtSceneDesc* desc, int device_id, RtScene** out_scene) {
+    if (!desc || !out_scene) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: null argument");
+    *out_scene = nullptr;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) return fail(RT_ERR_NO_DEVICE, "no HIP device is visible");
+    if (device_id < 0 || device_id >= n_dev) return fail(RT_ERR_NO_DEVICE, "device %d of %d does not exist", device_id, n_dev);
+    struct { const void* p; uint32_t n; const char* name; } arrays[] = {
+        {desc->lights, desc->n_lights, "lights"}, {desc->materials, desc->n_materials, "materials"},
+        {desc->planes, desc->n_planes, "planes"}, {desc->spheres, desc->n_spheres, "spheres"},
+        {desc->triangles, desc->n_triangles, "triangles"}, {desc->mesh_triangles, desc->n_mesh_triangles, "mesh_triangles"},
+        {desc->mesh_bvh_nodes, desc->n_mesh_bvh_nodes, "mesh_bvh_nodes"}, {desc->meshes, desc->n_meshes, "meshes"},
+        {desc->mesh_instances, desc->n_mesh_instances, "mesh_instances"}};
+    for (auto& a : arrays)
+        if (a.n && !a.p) return fail(RT_ERR_INVALID_ARGUMENT, "%s: %u elements but a null pointer", a.name, a.n);
+    if (desc->background.type > RT_BACKGROUND_COLORED_DIRECTION) return fail(RT_ERR_INVALID_ARGUMENT, "unknown background type %u", desc->background.type);
+
+    // ---- flatten on the host --------------------------------------------------------------------
+    std::vector<DLight> lights(desc->n_lights);
+    for (uint32_t i = 0; i < desc->n_lights; ++i) {
+        const RtLight& l = desc->lights[i];
+        DLight& o = lights[i];
+        memcpy(o.pos, l.position, 16);
+        for (int c = 0; c < 3; ++c) o.world[c] = l.position[c] / l.position[3];   // raytracer.rs:162
+        memcpy(o.ambient, l.ambient, 12); memcpy(o.diffuse, l.diffuse, 12); memcpy(o.specular, l.specular, 12);
+    }
+    std::vector<RtMaterial> materials(desc->materials, desc->materials + desc->n_materials);
+    for (uint32_t i = 0; i < desc->n_materials; ++i)
+        if (materials[i].material_type > RT_MATERIAL_REFLECT_AND_REFRACT)
+            return fail(RT_ERR_INVALID_ARGUMENT, "material %u: unknown material_type %u", i, materials[i].material_type);
+    std::vector<DPlane> planes(desc->n_planes);
+    for (uint32_t i = 0; i < desc->n_planes; ++i) {
+        const RtPlane& p = desc->planes[i];
+        if (p.material >= desc->n_materials) return fail(RT_ERR_OUT_OF_RANGE, "plane %u: material %u outside the %u materials", i, p.material, desc->n_materials);
+        memcpy(planes[i].n, p.normal, 12); planes[i].d = p.distance; planes[i].material = p.material;
+    }
+    std::vector<DSphere> spheres(desc->n_spheres);
+    for (uint32_t i = 0; i < desc->n_spheres; ++i) {
+        const RtSphere& p = desc->spheres[i];
+        if (p.material >= desc->n_materials) return fail(RT_ERR_OUT_OF_RANGE, "sphere %u: material %u outside the %u materials", i, p.material, desc->n_materials);
+        memcpy(spheres[i].c, p.center, 12); spheres[i].r = p.radius; spheres[i].material = p.material;
+    }
+    std::vector<DTriangle> triangles(desc->n_triangles);
+    for (uint32_t i = 0; i < desc->n_triangles; ++i) {
+        const RtTriangle& t = desc->triangles[i];
+        if (t.material >= desc->n_materials) return fail(RT_ERR_OUT_OF_RANGE, "triangle %u: material %u outside the %u materials", i, t.material, desc->n_materials);
+        DTriangle& o = triangles[i];
+        for (int c = 0; c < 3; ++c) {
+            o.p0[c] = t.vertices[0][c];
+            o.e1[c] = t.vertices[1][c] - t.vertices[0][c];
+            o.e2[c] = t.vertices[2][c] - t.vertices[0][c];
+            o.n0[c] = t.normals[0][c]; o.n1[c] = t.normals[1][c]; o.n2[c] = t.normals[2][c];
+            o.fn[c] = t.face_normal[c];
+        }
+        o.material = t.material;
+    }
+    std::vector<float4> nodes, hot, cold;
+    std::vector<MeshLayout> layouts(desc->n_meshes);
+    uint32_t stack_entries = 1;
+    for (uint32_t mi = 0; mi < desc->n_meshes; ++mi) {
+        int rc = layout_mesh(desc, mi, nodes, hot, cold, &layouts[mi]);
+        if (rc != RT_OK) return rc;
+    }
+    std::vector<DInstance> instances(desc->n_mesh_instances);
+    for (uint32_t i = 0; i < desc->n_mesh_instances; ++i) {
+        const RtMeshInstance& in = desc->mesh_instances[i];
+        if (in.mesh >= desc->n_meshes) return fail(RT_ERR_OUT_OF_RANGE, "mesh instance %u: mesh %u outside the %u meshes", i, in.mesh, desc->n_meshes);
+        if (in.material_override >= (int32_t)desc->n_materials || in.material_override < -1)
+            return fail(RT_ERR_OUT_OF_RANGE, "mesh instance %u: material_override %d outside the %u materials", i, in.material_override, desc->n_materials);
+        DInstance& o = instances[i];
+        mat34(in.model_inverse, &o.model_inverse);
+        mat34(in.rotation_scale_inverse, &o.rotation_scale_inverse);
+        mat34(in.model, &o.model);
+        mat34(in.rotation_scale, &o.rotation_scale);
+        o.root = layouts[in.mesh].root;
+        o.material_override = in.material_override;
+        if (layouts[in.mesh].stack_need > stack_entries) stack_entries = layouts[in.mesh].stack_need;
+    }
+    if (stack_entries > RT_BVH_STACK_LEN)
+        return fail(RT_ERR_BVH_TOO_DEEP, "a mesh BVH can need %u traversal stack entries; the reference's ArrayVec holds %d (intersect.rs:240)",
+                    stack_entries, RT_BVH_STACK_LEN);
+
+    // ---- upload ---------------------------------------------------------------------------------
+    HIP_TRY(hipSetDevice(device_id));
+    RtScene* s = new RtScene();
+    s->device = device_id;
+    int rc = RT_OK;
+    auto bail = [&](int code) { rt_scene_destroy(s); return code; };
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return bail(fail(RT_ERR_DEVICE, "hipGetDeviceProperties failed"));
+    s->n_cus = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&s->ev_start) != hipSuccess || hipEventCreate(&s->ev_stop) != hipSuccess)
+        return bail(fail(RT_ERR_DEVICE, "stream / event creation failed"));
+    s->d.background = desc->background;
+    s->d.n_lights = desc->n_lights; s->d.n_planes = desc->n_planes; s->d.n_spheres = desc->n_spheres;
+    s->d.n_triangles = desc->n_triangles; s->d.n_instances = desc->n_mesh_instances;
+    s->d.stack_entries = stack_entries;
+    if ((rc = upload(s, lights, &s->d.lights)) || (rc = upload(s, materials, &s->d.materials)) ||
+        (rc = upload(s, planes, &s->d.planes)) || (rc = upload(s, spheres, &s->d.spheres)) ||
+        (rc = upload(s, triangles, &s->d.triangles)) || (rc = upload(s, instances, &s->d.instances)) ||
+        (rc = upload(s, nodes, &s->d.nodes)) || (rc = upload(s, hot, &s->d.tri_hot)) || (rc = upload(s, cold, &s->d.tri_cold)))
+        return bail(rc);
+    int bpc = rt_query_trace_blocks_per_cu(stack_entries);
+    if (bpc < 1) return bail(fail(RT_ERR_DEVICE, "the trace kernel does not fit a compute unit"));
+    if (const char* env = getenv("RT_BLOCKS_PER_CU")) { int v = atoi(env); if (v >= 1 && v <= bpc) bpc = v; }
+    s->blocks_per_cu = bpc;
+    *out_scene = s;
+    return RT_OK;
+}
+
+extern "C" void rt_scene_destroy(RtScene* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->own_stream) (void)hipStreamSynchronize(s->own_stream);
+    if (s->last_stream) (void)hipStreamSynchronize(s->last_stream);
+    for (void* p : s->scene_allocs) (void)hipFree(p);
+    for (void* p : s->frame_allocs) (void)hipFree(p);
+    if (s->d_pixels) (void)hipFree(s->d_pixels);
+    if (s->d_aux_prim_out) (void)hipFree(s->d_aux_prim_out);
+    if (s->d_aux_inst_out) (void)hipFree(s->d_aux_inst_out);
+    if (s->d_aux_flags_out) (void)hipFree(s->d_aux_flags_out);
+    if (s->ev_start) (void)hipEventDestroy(s->ev_start);
+    if (s->ev_stop) (void)hipEventDestroy(s->ev_stop);
+    if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
+    delete s;
+}
+
+extern "C" int rt_scene_set_camera(RtScene* s, const float screen_to_world[16], uint32_t width, uint32_t height) {
+    if (!s || !screen_to_world) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_set_camera: null argument");
+    if (width == 0 || height == 0) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_set_camera: empty screen %ux%u", width, height);
+    memcpy(s->screen_to_world, screen_to_world, 64);
+    s->width = width;
+    s->height = height;
+    s->camera_set = true;
+    return RT_OK;
+}
+
+static uint32_t bytes_per_pixel(uint32_t format) { return format == RT_FORMAT_RGBA8 ? 4u : 3u; }
+
+struct Geometry { uint32_t tiles_x, tiles_y, shard_count, shard_index, tiles_per_shard, n_pixels; };
+
+static int frame_geometry(const RtScene* s, const RtRenderParams* p, bool sharded, Geometry* g) {
+    if (!s->camera_set) return fail(RT_ERR_INVALID_ARGUMENT, "the camera has not been set (rt_scene_set_camera)");
+    if (p->output_format > RT_FORMAT_RGBA8) return fail(RT_ERR_INVALID_ARGUMENT, "unknown output_format %u", p->output_format);
+    g->tiles_x = (s->width + RT_TILE_DIM - 1) / RT_TILE_DIM;
+    g->tiles_y = (s->height + RT_TILE_DIM - 1) / RT_TILE_DIM;
+    g->shard_count = (sharded && p->shard_count > 1) ? p->shard_count : 1;
+    g->shard_index = (g->shard_count > 1) ? p->shard_index : 0;
+    if (g->shard_index >= g->shard_count) return fail(RT_ERR_INVALID_ARGUMENT, "shard_index %u >= shard_count %u", g->shard_index, g->shard_count);
+    uint64_t tiles = (uint64_t)g->tiles_x * g->tiles_y;
+    g->tiles_per_shard = (uint32_t)((tiles + g->shard_count - 1) / g->shard_count);
+    uint64_t n_pixels = (uint64_t)g->tiles_per_shard * RT_TILE_DIM * RT_TILE_DIM;
+    if (n_pixels > RT_MAX_PIXELS_PER_SHARD) return fail(RT_ERR_INVALID_ARGUMENT, "%llu pixels per shard exceed the limit of %u", (unsigned long long)n_pixels, RT_MAX_PIXELS_PER_SHARD);
+    g->n_pixels = (uint32_t)n_pixels;
+    return RT_OK;
+}
+
+template <class T>
+static int frame_alloc(RtScene* s, size_t count, T** out) {
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, count * sizeof(T)));
+    s->frame_allocs.push_back(p);
+    *out = static_cast<T*>(p);
+    return RT_OK;
+}
+
+static int ensure_frame(RtScene* s, const Geometry& g, uint32_t max_depth, bool aux) {
+    uint32_t blocks = (uint32_t)(s->n_cus * s->blocks_per_cu);
+    uint32_t capacity = s->debug_queue_capacity ? s->debug_queue_capacity : (g.n_pixels > (1u << 28) / 4 ? (1u << 28) : 4 * g.n_pixels);
+    if (const char* env = getenv("RT_QUEUE_CAPACITY")) { long v = atol(env); if (v > 0 && !s->debug_queue_capacity) capacity = (uint32_t)v; }
+    RtScene::FrameKey k;
+    k.w = g.n_pixels; k.h = 0; k.shard_count = g.shard_count; k.max_depth = max_depth; k.aux = aux; k.blocks = blocks; k.capacity = capacity;
+    bool same = k.w == s->key.w && k.max_depth == s->key.max_depth && k.blocks == s->key.blocks && k.capacity == s->key.capacity &&
+                (s->key.aux || !aux) && !s->frame_allocs.empty();
+    if (!same) {
+        HIP_TRY(hipDeviceSynchronize());
+        for (void* p : s->frame_allocs) (void)hipFree(p);
+        s->frame_allocs.clear();
+        DFrame& f = s->f;
+        memset(&f, 0, sizeof(f));
+        int rc;
+        if ((rc = frame_alloc(s, (size_t)3 * g.n_pixels, &f.acc)) || (rc = frame_alloc(s, g.n_pixels, &f.poison)) ||
+            (rc = frame_alloc(s, (size_t)2 * capacity, &f.queue[0])) || (rc = frame_alloc(s, (size_t)2 * capacity, &f.queue[1])) ||
+            (rc = frame_alloc(s, (size_t)blocks * 256 * max_depth * 2, &f.spill)) || (rc = frame_alloc(s, 1, &f.counters)))
+            return rc;
+        if (aux && ((rc = frame_alloc(s, g.n_pixels, &f.aux_flags)) || (rc = frame_alloc(s, g.n_pixels, &f.aux_prim)) ||
+                    (rc = frame_alloc(s, g.n_pixels, &f.aux_inst))))
+            return rc;
+        s->key = k;
+    }
+    DFrame& f = s->f;
+    memcpy(f.screen_to_world, s->screen_to_world, 64);
+    f.width = s->width; f.height = s->height;
+    f.tiles_x = g.tiles_x; f.tiles_y = g.tiles_y;
+    f.shard_index = g.shard_index; f.shard_count = g.shard_count;
+    f.n_local_tiles = g.tiles_per_shard; f.n_pixels = g.n_pixels;
+    f.max_depth = max_depth;
+    f.queue_capacity = capacity;
+    return RT_OK;
+}
+
+// Enqueues one frame on `stream`: clear, one pass per recursion depth, resolve into d_out.
+static int enqueue_frame(RtScene* s, const RtRenderParams* p, bool sharded, bool aux, uint8_t* d_out) {
+    HIP_TRY(hipSetDevice(s->device));
+    Geometry g;
+    int rc = frame_geometry(s, p, sharded, &g);
+    if (rc) return rc;
+    uint32_t max_depth = p->max_depth ? p->max_depth : RT_DEFAULT_MAX_DEPTH;
+    if (max_depth > RT_MAX_DEPTH_LIMIT) return fail(RT_ERR_INVALID_ARGUMENT, "max_depth %u exceeds the limit of %d", max_depth, RT_MAX_DEPTH_LIMIT);
+    if ((rc = ensure_frame(s, g, max_depth, aux))) return rc;
+    hipStream_t stream = p->stream ? (hipStream_t)p->stream : s->own_stream;
+    s->last_stream = stream;
+    DFrame f = s->f;
+    if (!aux) f.aux_flags = f.aux_prim = f.aux_inst = nullptr;
+    uint32_t blocks = (uint32_t)(s->n_cus * s->blocks_per_cu);
+    HIP_TRY(hipEventRecord(s->ev_start, stream));
+    HIP_TRY(hipMemsetAsync(f.acc, 0, (size_t)3 * g.n_pixels * sizeof(long long), stream));
+    HIP_TRY(hipMemsetAsync(f.poison, 0, (size_t)g.n_pixels * sizeof(unsigned int), stream));
+    HIP_TRY(hipMemsetAsync(f.counters, 0, sizeof(DCounters), stream));
+    if (aux) HIP_TRY(hipMemsetAsync(f.aux_flags, 0, (size_t)g.n_pixels * sizeof(unsigned int), stream));
+    for (uint32_t level = 0; level < max_depth; ++level) {
+        if (level > 0) HIP_TRY(rt_launch_next_level(f.counters, level, stream));
+        HIP_TRY(rt_launch_trace_level(&s->d, &f, level, blocks, stream));
+    }
+    HIP_TRY(rt_launch_resolve(&f, d_out, bytes_per_pixel(p->output_format), g.shard_count > 1 ? 1u : 0u, stream));
+    HIP_TRY(hipEventRecord(s->ev_stop, stream));
+    s->timed = true;
+    return RT_OK;
+}
+
+extern "C" int rt_shard_bytes(const RtScene* s, const RtRenderParams* p, uint64_t* out_bytes) {
+    if (!s || !p || !out_bytes) return fail(RT_ERR_INVALID_ARGUMENT, "rt_shard_bytes: null argument");
+    Geometry g;
+    int rc = frame_geometry(s, p, true, &g);
+    if (rc) return rc;
+    if (g.shard_count > 1) *out_bytes = (uint64_t)g.n_pixels * bytes_per_pixel(p->output_format);
+    else *out_bytes = (uint64_t)s->width * s->height * bytes_per_pixel(p->output_format);
+    return RT_OK;
+}
+
+extern "C" int rt_render_device(RtScene* s, const RtRenderParams* p, void* d_out) {
+    if (!s || !p || !d_out) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_device: null argument");
+    return enqueue_frame(s, p, true, false, static_cast<uint8_t*>(d_out));
+}
+
+extern "C" int rt_render(RtScene* s, const RtRenderParams* p, uint8_t* out_pixels, RtAux* aux) {
+    if (!s || !p || !out_pixels) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: null argument");
+    HIP_TRY(hipSetDevice(s->device));
+    if (!s->camera_set) return fail(RT_ERR_INVALID_ARGUMENT, "the camera has not been set (rt_scene_set_camera)");
+    size_t n = (size_t)s->width * s->height;
+    size_t bytes = n * bytes_per_pixel(p->output_format);
+    if (s->d_pixels_bytes < bytes) {
+        if (s->d_pixels) (void)hipFree(s->d_pixels);
+        s->d_pixels = nullptr; s->d_pixels_bytes = 0;
+        HIP_TRY(hipMalloc((void**)&s->d_pixels, bytes));
+        s->d_pixels_bytes = bytes;
+    }
+    bool want_aux = aux && (aux->prim_id || aux->instance_id || aux->flags);
+    int rc = enqueue_frame(s, p, false, want_aux, s->d_pixels);
+    if (rc) return rc;
+    hipStream_t stream = s->last_stream;
+    if (want_aux) {
+        if (s->aux_out_pixels < n) {
+            if (s->d_aux_prim_out) (void)hipFree(s->d_aux_prim_out);
+            if (s->d_aux_inst_out) (void)hipFree(s->d_aux_inst_out);
+            if (s->d_aux_flags_out) (void)hipFree(s->d_aux_flags_out);
+            s->d_aux_prim_out = s->d_aux_inst_out = nullptr; s->d_aux_flags_out = nullptr; s->aux_out_pixels = 0;
+            HIP_TRY(hipMalloc((void**)&s->d_aux_prim_out, n * 4));
+            HIP_TRY(hipMalloc((void**)&s->d_aux_inst_out, n * 4));
+            HIP_TRY(hipMalloc((void**)&s->d_aux_flags_out, n));
+            s->aux_out_pixels = n;
+        }
+        DFrame f = s->f;
+        HIP_TRY(rt_launch_resolve_aux(&f, s->d_aux_prim_out, s->d_aux_inst_out, s->d_aux_flags_out, stream));
+        if (aux->prim_id) HIP_TRY(hipMemcpyAsync(aux->prim_id, s->d_aux_prim_out, n * 4, hipMemcpyDeviceToHost, stream));
+        if (aux->instance_id) HIP_TRY(hipMemcpyAsync(aux->instance_id, s->d_aux_inst_out, n * 4, hipMemcpyDeviceToHost, stream));
+        if (aux->flags) HIP_TRY(hipMemcpyAsync(aux->flags, s->d_aux_flags_out, n, hipMemcpyDeviceToHost, stream));
+    }
+    HIP_TRY(hipMemcpyAsync(out_pixels, s->d_pixels, bytes, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (aux) {
+        memset(aux->counters, 0, sizeof(aux->counters));
+        rc = rt_last_ray_counts(s, aux->counters);
+    }
+    return rc;
+}
+
+extern "C" int rt_assemble_shards(RtScene* s, const RtRenderParams* p, const void* d_gathered, void* d_frame) {
+    if (!s || !p || !d_gathered || !d_frame) return fail(RT_ERR_INVALID_ARGUMENT, "rt_assemble_shards: null argument");
+    HIP_TRY(hipSetDevice(s->device));
+    Geometry g;
+    int rc = frame_geometry(s, p, true, &g);
+    if (rc) return rc;
+    hipStream_t stream = p->stream ? (hipStream_t)p->stream : s->own_stream;
+    uint32_t bpp = bytes_per_pixel(p->output_format);
+    if (g.shard_count <= 1) {
+        HIP_TRY(hipMemcpyAsync(d_frame, d_gathered, (size_t)s->width * s->height * bpp, hipMemcpyDeviceToDevice, stream));
+        return RT_OK;
+    }
+    HIP_TRY(rt_launch_assemble(static_cast<const uint8_t*>(d_gathered), static_cast<uint8_t*>(d_frame), s->width, s->height,
+                               g.tiles_x, g.shard_count, g.tiles_per_shard, bpp, stream));
+    return RT_OK;
+}
+
+extern "C" int rt_last_ray_counts(RtScene* s, uint64_t counters[RT_N_COUNTERS]) {
+    if (!s || !counters) return fail(RT_ERR_INVALID_ARGUMENT, "rt_last_ray_counts: null argument");
+    if (!s->timed) return fail(RT_ERR_INVALID_ARGUMENT, "nothing has been rendered on this handle yet");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->last_stream));
+    DCounters c;
+    HIP_TRY(hipMemcpy(&c, s->f.counters, sizeof(c), hipMemcpyDeviceToHost));
+    for (int k = 0; k < RT_N_COUNTERS; ++k) counters[k] = 0;
+    for (int k = 0; k < 5; ++k) counters[k] = c.rays[k];
+    return RT_OK;
+}
+
+extern "C" int rt_last_render_ms(RtScene* s, float* out_ms) {
+    if (!s || !out_ms) return fail(RT_ERR_INVALID_ARGUMENT, "rt_last_render_ms: null argument");
+    if (!s->timed) return fail(RT_ERR_INVALID_ARGUMENT, "nothing has been rendered on this handle yet");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipEventSynchronize(s->ev_stop));
+    HIP_TRY(hipEventElapsedTime(out_ms, s->ev_start, s->ev_stop));
+    return RT_OK;
+}
+
+// Debug aid for tests: caps the per-depth ray queue (0 restores the default of four rays per pixel)
+// and reports how many child rays did not fit and were traced by their parent lane instead.
+extern "C" int rt_debug_set_queue_capacity(RtScene* s, uint32_t capacity) {
+    if (!s) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_set_queue_capacity: null argument");
+    s->debug_queue_capacity = capacity;
+    return RT_OK;
+}
+
+extern "C" int rt_debug_last_spilled(RtScene* s, uint32_t* out) {
+    if (!s || !out) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_last_spilled: null argument");
+    if (!s->timed) return fail(RT_ERR_INVALID_ARGUMENT, "nothing has been rendered on this handle yet");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->last_stream));
+    DCounters c;
+    HIP_TRY(hipMemcpy(&c, s->f.counters, sizeof(c), hipMemcpyDeviceToHost));
+    *out = c.spilled;
+    return RT_OK;
+}
+
+extern "C" const char* rt_last_error(void) { return g_error; }

@@ -1,0 +1,104 @@
+// Device-side data layout of the gfx950 renderer, shared by the host upload code and the kernels.
+//
+// Everything the per-ray code reads is laid out for the way a wave64 reads it:
+//  * the few analytic primitives, lights and materials are small arrays read with wave-uniform
+//    indices (the compiler turns those into scalar loads);
+//  * BVH nodes are 32 B (two 16-B loads, two nodes per 64-B line);
+//  * mesh triangles are re-ordered so that the triangles of a leaf are consecutive, 48 B of "hot"
+//    data per triangle (first vertex and the two edge vectors the Moeller-Trumbore test starts
+//    from) and 48 B of "cold" data (normals) read only for the winning hit.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/rt_hip.h"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define RT_HD __host__ __device__
+#else
+#define RT_HD
+struct float4 { float x, y, z, w; };
+#endif
+
+#define RT_MAX_DEPTH_LIMIT 63      // depth is carried in 6 bits of a ray record
+#define RT_MAX_PIXELS_PER_SHARD (1u << 25)
+
+struct DLight {
+    float pos[4];          // RtLight::position
+    float world[3];        // position.xyz / position.w (raytracer.rs:162,177,215), unused when w == 0
+    float ambient[3];
+    float diffuse[3];
+    float specular[3];
+};
+
+struct DPlane { float n[3]; float d; uint32_t material; };
+struct DSphere { float c[3]; float r; uint32_t material; };
+
+// Scene::triangles (free triangles): vertex 0, edges, normals
+struct DTriangle {
+    float p0[3], e1[3], e2[3];
+    float n0[3], n1[3], n2[3];
+    float fn[3];
+    uint32_t material;
+};
+
+// 3x4 row-major top rows of a column-major Mat4: r[i][j] = M(i, j)
+struct DMat34 { float r[3][4]; };
+
+struct DInstance {
+    DMat34 model_inverse;
+    DMat34 rotation_scale_inverse;
+    DMat34 model;
+    DMat34 rotation_scale;
+    uint32_t root;              // device node index of the mesh root, 0xFFFFFFFF for an empty mesh
+    int32_t material_override;  // -1 = none
+};
+
+#define RT_NODE_LEAF_BIT 0x80000000u
+
+// Arrays in device memory.
+struct DScene {
+    RtBackground background;
+    uint32_t n_lights, n_planes, n_spheres, n_triangles, n_instances;
+    uint32_t stack_entries;      // per-lane traversal stack entries any mesh can need (<= RT_BVH_STACK_LEN)
+    const DLight* lights;
+    const RtMaterial* materials;
+    const DPlane* planes;
+    const DSphere* spheres;
+    const DTriangle* triangles;
+    const DInstance* instances;
+    // node i: nodes[2*i] = (min.xyz, bits a), nodes[2*i+1] = (max.xyz, bits b)
+    //   inner: a = left child, b = right child        leaf: a = first triangle slot, b = RT_NODE_LEAF_BIT | count
+    const float4* nodes;
+    // slot s: tri_hot[3*s] = (p0.xyz, e1.x), [3*s+1] = (e1.y, e1.z, e2.x, e2.y), [3*s+2] = (e2.z, bits mesh_triangle_index, bits material, 0)
+    const float4* tri_hot;
+    // slot s: tri_cold[3*s] = (n0.xyz, fn.x), [3*s+1] = (n1.xyz, fn.y), [3*s+2] = (n2.xyz, fn.z)
+    const float4* tri_cold;
+};
+
+// Per-frame device state.
+struct DCounters {
+    unsigned long long rays[5];      // RT_CTR_RAYS .. RT_CTR_TRANSMITTED
+    unsigned int queue_count[2];     // rays appended to each of the two queues (may exceed capacity)
+    unsigned int cursor;             // next input index handed out in the running pass
+    unsigned int spilled;            // children that did not fit the queue and were traced by their parent lane
+};
+
+struct DFrame {
+    float screen_to_world[16];       // column-major
+    uint32_t width, height;
+    uint32_t tiles_x, tiles_y;
+    uint32_t shard_index, shard_count;
+    uint32_t n_local_tiles;          // tiles this shard owns (rounded up so every shard has the same number)
+    uint32_t n_pixels;               // n_local_tiles * RT_TILE_DIM^2
+    uint32_t max_depth;
+    uint32_t queue_capacity;
+    long long* acc;                  // [3][n_pixels] fixed-point colour sums, 2^-40 units
+    unsigned int* poison;            // [n_pixels] non-finite contributions, see rt_kernels.hip
+    unsigned int* aux_flags;         // [n_pixels] or null
+    unsigned int* aux_prim;          // [n_pixels] or null
+    unsigned int* aux_inst;          // [n_pixels] or null
+    float4* queue[2];                // ray records, 2 float4 each
+    float4* spill;                   // [threads][max_depth][2]
+    DCounters* counters;
+};

@@ -17,7 +17,7 @@ def model_dir(tmp_path_factory):
     """Directory with small stand-in OBJ files (low subdivision levels keep CPU tests fast)."""
     from rust_raytracer_amd import meshes
     d = tmp_path_factory.mktemp("models")
-    return meshes.ensure_model_dir(str(d), levels={"bunny.obj": 3, "santa.obj": 3, "sphere_high.obj": 3,
+    return meshes.ensure_model_dir(str(d), levels={"bunny.obj": 4, "santa.obj": 4, "sphere_high.obj": 3,
                                                    "sphere_low.obj": 1})
 
 
