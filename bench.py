@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s (primary + secondary) on reflective_bunnies at 1920x1080.
+
+One step = one frame of the workload.  With N ranks (one per GPU) the frame is tile-sharded: rank r
+renders the 32x32 tiles t with t % N == r of the same frame, the shard buffers are all-gathered over
+RCCL and every rank assembles the frame - the total work is fixed, so scaling is "strong".
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints one JSON line.  The scene's bunny.obj is not part of the reference repository; a
+deterministic stand-in of 81 920 triangles is generated (rust_raytracer_amd/meshes.py) unless a real
+bunny.obj is found in --model-dir.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: scene file, width, height, max_depth
+    "reflective_bunnies_1080p": ("reflective_bunnies.json", 1920, 1080, 10),
+    "cornell_box_720p": ("cornell_box.json", 1280, 720, 10),
+    "mirror_sphere_1080p_depth16": ("mirror_sphere.json", 1920, 1080, 16),
+    "infinity_santa_1080p_depth16": ("infinity_santa.json", 1920, 1080, 16),
+}
+
+# Algorithmic work of the reference's un-pruned traversal (what intersect.rs would execute), per
+# unit of the metric (one ray = one Scene::intersect call):
+#   bytes = 32*aabb_tests + 36*mesh_triangle_tests + 48*mesh_hits + 256*instance_transforms + 3*W*H
+#   flops = 27*aabb_tests + 57*(mesh_triangle_tests + triangle_tests) + 40*sphere_tests + 14*plane_tests
+#           + 90*instance_transforms + 60*light_shades
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E
+FP32_NO_FMA_PEAK_TFLOPS = 78.6   # 157.3 TFLOP/s vector FP32 counts an FMA as two; contraction is forbidden here
+
+
+def algorithmic_work(counters, width, height):
+    from rust_raytracer_amd import abi
+    c = {n: int(v) for n, v in zip(abi.COUNTER_NAMES, counters)}
+    nbytes = (32 * c["aabb_tests"] + 36 * c["mesh_triangle_tests"] + 48 * c["mesh_hits"]
+              + 256 * c["instance_transforms"] + 3 * width * height)
+    flops = (27 * c["aabb_tests"] + 57 * (c["mesh_triangle_tests"] + c["triangle_tests"]) + 40 * c["sphere_tests"]
+             + 14 * c["plane_tests"] + 90 * c["instance_transforms"] + 60 * c["light_shades"])
+    return nbytes, flops, c
+
+
+def cpu_baseline(scene_path, model_dir, width, height, max_depth, budget_s=12.0):
+    """The CPU oracle (C++ restatement of the reference renderer, row-parallel like native_app's
+    rayon loop) timed on this host; also returns its un-pruned traversal statistics."""
+    from oracle import orc
+    s = orc.OracleScene.from_file(scene_path, model_dir)
+    s.resize(width, height)
+    cores = min(len(os.sched_getaffinity(0)), 16)
+    t0 = time.perf_counter()
+    r = s.render(max_depth, threads=cores, aux=False)
+    dt = time.perf_counter() - t0
+    frames, total = 1, dt
+    best = dt
+    while total + best < budget_s and frames < 8:
+        t0 = time.perf_counter()
+        s.render(max_depth, threads=cores, aux=False)
+        d = time.perf_counter() - t0
+        best = min(best, d)
+        total += d
+        frames += 1
+    rays = int(r["counters"][0])
+    return {"value": rays / best / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": "%d full %dx%d frames of the workload (%.2f s best, %d rays each), C++ oracle, %d threads"
+                      % (frames, width, height, best, rays, cores)}, r["counters"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="reflective_bunnies_1080p", choices=sorted(WORKLOADS))
+    ap.add_argument("--model-dir", default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from rust_raytracer_amd import meshes, native, sharding
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("--gpus %d needs a launch with torch.distributed.run (one rank per GPU)" % args.gpus)
+        sys.exit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    scene_file, width, height, max_depth = WORKLOADS[args.workload]
+    scene_path = os.path.join(ROOT, "scenes", scene_file)
+    model_dir = args.model_dir
+    if model_dir is None:
+        model_dir = meshes.ensure_model_dir(os.path.join("/tmp", "rust_raytracer_amd_models_rank%d_%d" % (rank, os.getuid())))
+
+    host = native.HostScene.load(scene_path, model_dir)
+    host.resize_screen(width, height)
+    dev = native.DeviceScene(host.desc(), local_rank)
+    m, w, h = host.camera()
+    dev.set_camera(m, w, h)
+    n_tris = host.desc().n_mesh_triangles
+
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    handle = stream.cuda_stream
+
+    def render_shard(out):
+        dev.render_device(out.data_ptr(), max_depth=max_depth, shard_index=rank, shard_count=world, stream=handle)
+
+    def assemble(gathered, frame):
+        dev.assemble_shards(gathered.data_ptr(), frame.data_ptr(), world, stream=handle)
+
+    sf = sharding.ShardedFrame(w, h, 3, rank, world, "cuda", render_shard, assemble)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        sf.step()
+    barrier()
+    trace_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sf.step()
+        # HIP events recorded by the library on the launch stream; reading them back does not
+        # synchronise (the elapsed times are collected after the timed region)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    # kernel time of the last frame's trace launches, from the library's HIP events
+    trace_ms = dev.last_trace_ms()
+    frame_ms = dev.last_render_ms()
+    counts = dev.last_ray_counts().astype(np.int64)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    rays = torch.tensor(counts[:5], dtype=torch.int64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(rays, op=dist.ReduceOp.SUM)
+    elapsed = float(t.item())
+    rays = rays.cpu().numpy()
+    frame_check = sf.frame.cpu().numpy().reshape(h, w, 3)
+
+    if rank == 0:
+        rays_per_frame = int(rays[0])
+        value = rays_per_frame * args.steps / elapsed / 1e6
+        out = {
+            "metric": "Mrays/s (primary+secondary) at 1080p reflective_bunnies" if args.workload == "reflective_bunnies_1080p"
+                      else "Mrays/s (primary+secondary) " + args.workload,
+            "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "scene": scene_file, "width": w, "height": h, "max_depth": max_depth,
+                       "mesh": "bunny.obj stand-in (procedural, %d triangles) unless --model-dir holds a real one" % n_tris
+                               if n_tris else "none",
+                       "rays_per_frame": rays_per_frame, "primary": int(rays[1]), "shadow": int(rays[2]),
+                       "reflected": int(rays[3]), "transmitted": int(rays[4]),
+                       "parallelism": "tile-sharded x%d, scene replicated, RCCL all-gather" % world if world > 1 else "single GPU"},
+        }
+        baseline = None
+        ref_counters = None
+        if not args.no_cpu_baseline and world == 1:
+            baseline, ref_counters = cpu_baseline(scene_path, model_dir, w, h, max_depth)
+            out["cpu_baseline"] = baseline
+            # the frame the GPU produced must agree with the oracle's ray statistics
+            assert [int(x) for x in ref_counters[:5]] == [int(x) for x in rays[:5]], "ray counts differ from the oracle"
+        roofline = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                    "kernel": "rt_trace_level", "launches_per_frame": max_depth,
+                    "avg_launch_ms": trace_ms / max_depth, "frame_kernel_ms": frame_ms}
+        if ref_counters is not None:
+            nbytes, flops, c = algorithmic_work(ref_counters, w, h)
+            per_launch = nbytes / max_depth
+            roofline["achieved"] = per_launch / (trace_ms / max_depth * 1e-3) / 1e9
+            roofline["frac"] = roofline["achieved"] / HBM_PEAK_GBS
+            roofline["algorithmic_bytes_per_ray"] = nbytes / rays_per_frame
+            roofline["algorithmic_flops_per_ray"] = flops / rays_per_frame
+            roofline["valu"] = {"achieved": flops / (trace_ms * 1e-3) / 1e12, "peak": FP32_NO_FMA_PEAK_TFLOPS,
+                                "unit": "TFLOP/s", "frac": flops / (trace_ms * 1e-3) / 1e12 / FP32_NO_FMA_PEAK_TFLOPS}
+        traffic_file = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+        if os.path.exists(traffic_file):
+            roofline["traffic"] = json.load(open(traffic_file)).get("hbm_bytes_per_launch")
+        out["roofline"] = roofline
+        out["frame_checksum"] = int(np.asarray(frame_check, dtype=np.uint64).sum())
+        print(json.dumps(out))
+    dev.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

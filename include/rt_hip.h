@@ -247,6 +247,10 @@ int rt_last_ray_counts(RtScene* scene, uint64_t counters[RT_N_COUNTERS]);
  * enqueued command, measured with HIP events on the stream the kernels ran on. */
 int rt_last_render_ms(RtScene* scene, float* out_ms);
 
+/* The part of rt_last_render_ms spent in the per-depth trace launches (max_depth launches of the
+ * one kernel that does all intersection and shading work), measured the same way. */
+int rt_last_trace_ms(RtScene* scene, float* out_ms);
+
 void rt_scene_destroy(RtScene* scene);
 
 /* Test aids.  The first caps the per-depth ray queue at `capacity` rays (0 = the default, four rays

@@ -41,7 +41,7 @@ static int fail(int code, const char* fmt, ...) {
 struct RtScene {
     int device = 0;
     hipStream_t own_stream = nullptr;
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_trace_start = nullptr, ev_trace_stop = nullptr;
     bool timed = false;
     hipStream_t last_stream = nullptr;
     int n_cus = 0;
@@ -247,7 +247,8 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device_id, RtScene**
     if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return bail(fail(RT_ERR_DEVICE, "hipGetDeviceProperties failed"));
     s->n_cus = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreate(&s->ev_start) != hipSuccess || hipEventCreate(&s->ev_stop) != hipSuccess)
+        hipEventCreate(&s->ev_start) != hipSuccess || hipEventCreate(&s->ev_stop) != hipSuccess ||
+        hipEventCreate(&s->ev_trace_start) != hipSuccess || hipEventCreate(&s->ev_trace_stop) != hipSuccess)
         return bail(fail(RT_ERR_DEVICE, "stream / event creation failed"));
     s->d.background = desc->background;
     s->d.n_lights = desc->n_lights; s->d.n_planes = desc->n_planes; s->d.n_spheres = desc->n_spheres;
@@ -279,6 +280,8 @@ extern "C" void rt_scene_destroy(RtScene* s) {
     if (s->d_aux_flags_out) (void)hipFree(s->d_aux_flags_out);
     if (s->ev_start) (void)hipEventDestroy(s->ev_start);
     if (s->ev_stop) (void)hipEventDestroy(s->ev_stop);
+    if (s->ev_trace_start) (void)hipEventDestroy(s->ev_trace_start);
+    if (s->ev_trace_stop) (void)hipEventDestroy(s->ev_trace_stop);
     if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
     delete s;
 }
@@ -376,10 +379,12 @@ static int enqueue_frame(RtScene* s, const RtRenderParams* p, bool sharded, bool
     HIP_TRY(hipMemsetAsync(f.poison, 0, (size_t)g.n_pixels * sizeof(unsigned int), stream));
     HIP_TRY(hipMemsetAsync(f.counters, 0, sizeof(DCounters), stream));
     if (aux) HIP_TRY(hipMemsetAsync(f.aux_flags, 0, (size_t)g.n_pixels * sizeof(unsigned int), stream));
+    HIP_TRY(hipEventRecord(s->ev_trace_start, stream));
     for (uint32_t level = 0; level < max_depth; ++level) {
         if (level > 0) HIP_TRY(rt_launch_next_level(f.counters, level, stream));
         HIP_TRY(rt_launch_trace_level(&s->d, &f, level, blocks, stream));
     }
+    HIP_TRY(hipEventRecord(s->ev_trace_stop, stream));
     HIP_TRY(rt_launch_resolve(&f, d_out, bytes_per_pixel(p->output_format), g.shard_count > 1 ? 1u : 0u, stream));
     HIP_TRY(hipEventRecord(s->ev_stop, stream));
     s->timed = true;
@@ -481,6 +486,15 @@ extern "C" int rt_last_render_ms(RtScene* s, float* out_ms) {
     return RT_OK;
 }
 
+extern "C" int rt_last_trace_ms(RtScene* s, float* out_ms) {
+    if (!s || !out_ms) return fail(RT_ERR_INVALID_ARGUMENT, "rt_last_trace_ms: null argument");
+    if (!s->timed) return fail(RT_ERR_INVALID_ARGUMENT, "nothing has been rendered on this handle yet");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipEventSynchronize(s->ev_trace_stop));
+    HIP_TRY(hipEventElapsedTime(out_ms, s->ev_trace_start, s->ev_trace_stop));
+    return RT_OK;
+}
+
 // Debug aid for tests: caps the per-depth ray queue (0 restores the default of four rays per pixel)
 // and reports how many child rays did not fit and were traced by their parent lane instead.
 extern "C" int rt_debug_set_queue_capacity(RtScene* s, uint32_t capacity) {
@@ -501,3 +515,6 @@ extern "C" int rt_debug_last_spilled(RtScene* s, uint32_t* out) {
 }
 
 extern "C" const char* rt_last_error(void) { return g_error; }
+
+// shared with host/rt_host.cpp so that both halves of the library report through rt_last_error()
+extern "C" char* rt_internal_error_buffer(void) { return g_error; }

@@ -14,8 +14,18 @@ LIB_PATH = os.path.join(_HERE, "librt_hip.so")
 
 # every function include/rt_hip.h declares
 EXPORTS = ["rt_scene_create", "rt_scene_set_camera", "rt_render", "rt_render_device", "rt_shard_bytes",
-           "rt_assemble_shards", "rt_last_ray_counts", "rt_last_render_ms", "rt_scene_destroy",
+           "rt_assemble_shards", "rt_last_ray_counts", "rt_last_render_ms", "rt_last_trace_ms", "rt_scene_destroy",
            "rt_debug_set_queue_capacity", "rt_debug_last_spilled", "rt_last_error"]
+# every function include/rt_host.h declares
+HOST_EXPORTS = ["rt_host_scene_parse", "rt_host_scene_load", "rt_host_scene_desc", "rt_host_scene_camera",
+                "rt_host_scene_resize_screen", "rt_host_scene_turn_camera", "rt_host_scene_set_camera_pose",
+                "rt_host_scene_get_camera_pose", "rt_host_scene_find_material", "rt_host_scene_find_mesh",
+                "rt_host_scene_add_instance", "rt_host_scene_add_mesh", "rt_host_scene_destroy"]
+
+# RtMeshLoadFn of include/rt_host.h
+RELEASE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t)
+MESH_LOAD_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                           C.POINTER(RELEASE_FN))
 
 _LIB = None
 
@@ -42,11 +52,27 @@ def lib():
         L.rt_assemble_shards.argtypes = [vp, C.POINTER(abi.RtRenderParams), vp, vp]
         L.rt_last_ray_counts.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.rt_last_render_ms.argtypes = [vp, C.POINTER(C.c_float)]
+        L.rt_last_trace_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.rt_scene_destroy.argtypes = [vp]
         L.rt_scene_destroy.restype = None
         L.rt_debug_set_queue_capacity.argtypes = [vp, u32]
         L.rt_debug_last_spilled.argtypes = [vp, C.POINTER(u32)]
         L.rt_last_error.restype = C.c_char_p
+        fp = C.POINTER(C.c_float)
+        L.rt_host_scene_parse.argtypes = [C.c_char_p, C.c_size_t, MESH_LOAD_FN, vp, C.POINTER(vp)]
+        L.rt_host_scene_load.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(vp)]
+        L.rt_host_scene_desc.argtypes = [vp, C.POINTER(abi.RtSceneDesc)]
+        L.rt_host_scene_camera.argtypes = [vp, fp, C.POINTER(u32), C.POINTER(u32)]
+        L.rt_host_scene_resize_screen.argtypes = [vp, u32, u32]
+        L.rt_host_scene_turn_camera.argtypes = [vp] + [C.c_float] * 4
+        L.rt_host_scene_set_camera_pose.argtypes = [vp, fp, fp]
+        L.rt_host_scene_get_camera_pose.argtypes = [vp, fp, fp]
+        L.rt_host_scene_find_material.argtypes = [vp, C.c_char_p]
+        L.rt_host_scene_find_mesh.argtypes = [vp, C.c_char_p]
+        L.rt_host_scene_add_instance.argtypes = [vp, u32, fp, fp, fp, C.c_int32]
+        L.rt_host_scene_add_mesh.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_size_t, u32, C.c_int]
+        L.rt_host_scene_destroy.argtypes = [vp]
+        L.rt_host_scene_destroy.restype = None
         _LIB = L
     return _LIB
 
@@ -130,6 +156,11 @@ class DeviceScene:
         check(lib().rt_last_render_ms(self._h, C.byref(ms)))
         return float(ms.value)
 
+    def last_trace_ms(self) -> float:
+        ms = C.c_float()
+        check(lib().rt_last_trace_ms(self._h, C.byref(ms)))
+        return float(ms.value)
+
     def debug_set_queue_capacity(self, capacity: int):
         check(lib().rt_debug_set_queue_capacity(self._h, capacity))
 
@@ -137,3 +168,96 @@ class DeviceScene:
         n = C.c_uint32()
         check(lib().rt_debug_last_spilled(self._h, C.byref(n)))
         return int(n.value)
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+class HostScene:
+    """Owner of one RtHostScene: a lib_raytracer::Scene built by the library's own loader."""
+
+    def __init__(self, handle):
+        self._h = handle
+        self._keep = []
+
+    @classmethod
+    def load(cls, json_path: str, model_dir: str = ""):
+        """Parser::parse_json with native_app's FilesystemMeshLoader."""
+        h = C.c_void_p()
+        check(lib().rt_host_scene_load(json_path.encode(), model_dir.encode(), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def parse(cls, json_text: str, mesh_loader=None):
+        """Parser::parse_json with `mesh_loader(file_name) -> bytes | str | None` as the MeshLoader."""
+        h = C.c_void_p()
+        kept = []
+
+        def load(_user, file_name, out_data, out_len, out_release):
+            data = mesh_loader(file_name.decode()) if mesh_loader else None
+            if data is None:
+                return 1
+            if isinstance(data, str):
+                data = data.encode()
+            buf = C.create_string_buffer(data, len(data))
+            kept.append(buf)
+            out_data[0] = C.cast(buf, C.c_void_p)
+            out_len[0] = len(data)
+            out_release[0] = RELEASE_FN(0)
+            return 0
+
+        text = json_text.encode()
+        check(lib().rt_host_scene_parse(text, len(text), MESH_LOAD_FN(load), None, C.byref(h)))
+        return cls(h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rt_host_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def desc(self) -> abi.RtSceneDesc:
+        d = abi.RtSceneDesc()
+        check(lib().rt_host_scene_desc(self._h, C.byref(d)))
+        return d
+
+    def camera(self):
+        m = (C.c_float * 16)()
+        w, h = C.c_uint32(), C.c_uint32()
+        check(lib().rt_host_scene_camera(self._h, m, C.byref(w), C.byref(h)))
+        return np.array(m, dtype=np.float32), int(w.value), int(h.value)
+
+    def resize_screen(self, width: int, height: int):
+        check(lib().rt_host_scene_resize_screen(self._h, width, height))
+
+    def turn_camera(self, begin_x, begin_y, end_x, end_y):
+        check(lib().rt_host_scene_turn_camera(self._h, begin_x, begin_y, end_x, end_y))
+
+    def set_camera_pose(self, position=None, orientation=None):
+        check(lib().rt_host_scene_set_camera_pose(self._h, _f3(position) if position is not None else None,
+                                                  _f3(orientation) if orientation is not None else None))
+
+    def camera_pose(self):
+        p, o = (C.c_float * 3)(), (C.c_float * 3)()
+        check(lib().rt_host_scene_get_camera_pose(self._h, p, o))
+        return np.array(p, dtype=np.float32), np.array(o, dtype=np.float32)
+
+    def find_material(self, name: str) -> int:
+        return lib().rt_host_scene_find_material(self._h, name.encode())
+
+    def find_mesh(self, name: str) -> int:
+        return lib().rt_host_scene_find_mesh(self._h, name.encode())
+
+    def add_instance(self, mesh: int, position, orientation, scale, material_override: int = -1):
+        check(lib().rt_host_scene_add_instance(self._h, mesh, _f3(position), _f3(orientation), _f3(scale),
+                                               material_override))
+
+    def add_mesh(self, name: str, obj_text, material: int, counter_clockwise: bool = True):
+        data = obj_text.encode() if isinstance(obj_text, str) else obj_text
+        check(lib().rt_host_scene_add_mesh(self._h, name.encode(), data, len(data), material, int(counter_clockwise)))

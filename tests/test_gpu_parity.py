@@ -120,3 +120,38 @@ def test_rgba_and_repeatability(scenes_dir, model_dir):
     assert np.array_equal(a, b)                      # integer accumulation: no run-to-run variation
     assert np.array_equal(a[..., :3], c)
     assert (a[..., 3] == 255).all()                  # web_app/wasm/src/color.rs:10-21
+
+
+@pytest.mark.parametrize("shards", [2, 3, 8])
+def test_tile_shards_assemble_to_the_same_frame(scenes_dir, model_dir, shards):
+    """rt_render_device with shard_index / shard_count + rt_assemble_shards: byte-identical to the
+    unsharded frame for any number of shards (here all shards are rendered by the one GPU)."""
+    import torch
+    from rust_raytracer_amd import sharding
+    s = load(scenes_dir, model_dir, "reflective_bunnies", 333, 245)
+    m, w, h = s.camera()
+    dev = native.DeviceScene(s.desc(), 0)
+    try:
+        dev.set_camera(m, w, h)
+        whole = dev.render(channels=3)["rgb"]
+        side = torch.cuda.Stream()                 # a real stream handle: NULL would select the handle's own stream
+        torch.cuda.set_stream(side)
+        stream = side.cuda_stream
+        nbytes = dev.shard_bytes(shards)
+        assert nbytes == sharding.shard_bytes(w, h, shards)
+        gathered = torch.zeros(shards * nbytes, dtype=torch.uint8, device="cuda")
+        for r in range(shards):
+            part = gathered[r * nbytes:(r + 1) * nbytes]
+            dev.render_device(part.data_ptr(), shard_index=r, shard_count=shards, stream=stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(part.cpu().numpy(), sharding.extract_shard(whole, r, shards))
+        frame = torch.zeros(h * w * 3, dtype=torch.uint8, device="cuda")
+        dev.assemble_shards(gathered.data_ptr(), frame.data_ptr(), shards, stream=stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(frame.cpu().numpy().reshape(h, w, 3), whole)
+        full = torch.zeros(h * w * 3, dtype=torch.uint8, device="cuda")
+        dev.render_device(full.data_ptr(), stream=stream)                     # shard_count 1: row-major frame
+        torch.cuda.synchronize()
+        assert np.array_equal(full.cpu().numpy().reshape(h, w, 3), whole)
+    finally:
+        dev.close()
