@@ -3,6 +3,7 @@
 // run, every entry point fails with RT_ERR_DEVICE / RT_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -84,14 +85,20 @@ static float4 f4(float x, float y, float z, float w) { float4 r; r.x = x; r.y = 
 static float bits(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
 namespace {
-// Re-lays one mesh's BVH out in the order the reference visits it (pop, push left, push right:
-// intersect.rs:245-256, i.e. right-first pre-order) with the triangles of a leaf made consecutive.
+// One mesh's BVH re-laid out for the device (see DScene in rt_device.h).
 struct MeshLayout {
-    uint32_t root = 0xFFFFFFFFu;
+    uint32_t root_ref = RT_REF_NONE;
+    float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};
     uint32_t stack_need = 1;
+    float max_edge_product = 0.0f;   // max |e1| * |e2| over the mesh's triangles
+    float max_edge_sum = 0.0f;       // max |e1| + |e2|
 };
 }  // namespace
 
+// Walks the mesh's tree in the order the reference's traversal visits it (pop, push left, push right:
+// intersect.rs:245-256, i.e. right-first pre-order).  Inner nodes are numbered in that order, the
+// triangles of each leaf get consecutive slots in that order - so a lower slot means "visited earlier
+// by the reference", which is what decides ties there (utils/mod.rs:17).
 static int layout_mesh(const RtSceneDesc* desc, uint32_t mesh_index, std::vector<float4>& nodes, std::vector<float4>& hot,
                        std::vector<float4>& cold, MeshLayout* out) {
     const RtMesh& m = desc->meshes[mesh_index];
@@ -99,29 +106,28 @@ static int layout_mesh(const RtSceneDesc* desc, uint32_t mesh_index, std::vector
         return fail(RT_ERR_OUT_OF_RANGE, "mesh %u: node range [%u, %u) outside the %u nodes", mesh_index, m.node_begin,
                     m.node_end, desc->n_mesh_bvh_nodes);
     if (m.node_begin == m.node_end) return RT_OK;            // empty BVH: never hit (intersect.rs:235-237)
-    struct Item { uint32_t src; uint32_t parent_slot; bool right; };
+    struct Item { uint32_t src; uint32_t parent; bool right; uint32_t depth; };
     std::vector<Item> stack;
-    stack.push_back({m.node_begin, 0xFFFFFFFFu, false});
-    size_t visited = 0, max_sp = 1;
+    stack.push_back({m.node_begin, 0xFFFFFFFFu, false, 0});
+    size_t visited = 0;
+    uint32_t need = 1;
     const size_t budget = 4 * (size_t)(m.node_end - m.node_begin) + 16;
+    auto check_node = [&](uint32_t i) { return i < desc->n_mesh_bvh_nodes; };
     while (!stack.empty()) {
         Item it = stack.back();
         stack.pop_back();
-        if (it.src >= desc->n_mesh_bvh_nodes)
+        if (!check_node(it.src))
             return fail(RT_ERR_OUT_OF_RANGE, "mesh %u: BVH node index %u outside the %u nodes", mesh_index, it.src,
                         desc->n_mesh_bvh_nodes);
         if (++visited > budget) return fail(RT_ERR_INVALID_ARGUMENT, "mesh %u: BVH is not a tree", mesh_index);
         const RtBvhNode& n = desc->mesh_bvh_nodes[it.src];
-        uint32_t dev = (uint32_t)(nodes.size() / 2);
-        if (it.parent_slot == 0xFFFFFFFFu) out->root = dev;
-        else {
-            float4& p = nodes[2 * (size_t)it.parent_slot + (it.right ? 1 : 0)];
-            p.w = bits(dev);
-        }
+        uint32_t ref;
         if (n.is_leaf) {
             if (n.triangle_count > RT_LEAF_TRIANGLES)
                 return fail(RT_ERR_INVALID_ARGUMENT, "mesh %u: leaf with %u triangles", mesh_index, n.triangle_count);
-            uint32_t first = (uint32_t)(hot.size() / 3);
+            size_t first = hot.size() / 3;
+            if (first + n.triangle_count > RT_REF_SLOT_MASK)
+                return fail(RT_ERR_INVALID_ARGUMENT, "more than %u mesh triangles", RT_REF_SLOT_MASK);
             for (uint32_t k = 0; k < n.triangle_count; ++k) {
                 uint32_t ti = n.triangle_indices[k];
                 if (ti >= desc->n_mesh_triangles)
@@ -141,18 +147,39 @@ static int layout_mesh(const RtSceneDesc* desc, uint32_t mesh_index, std::vector
                 cold.push_back(f4(t.normals[0][0], t.normals[0][1], t.normals[0][2], bits(ti)));
                 cold.push_back(f4(t.normals[1][0], t.normals[1][1], t.normals[1][2], bits(t.material)));
                 cold.push_back(f4(t.normals[2][0], t.normals[2][1], t.normals[2][2], 0.0f));
+                double l1 = std::sqrt((double)e1[0] * e1[0] + (double)e1[1] * e1[1] + (double)e1[2] * e1[2]);
+                double l2 = std::sqrt((double)e2[0] * e2[0] + (double)e2[1] * e2[1] + (double)e2[2] * e2[2]);
+                float prod = (float)(l1 * l2), sum = (float)(l1 + l2);
+                if (!(prod <= out->max_edge_product)) out->max_edge_product = prod;      // NaN sticks
+                if (!(sum <= out->max_edge_sum)) out->max_edge_sum = sum;
             }
-            nodes.push_back(f4(n.aabb_min[0], n.aabb_min[1], n.aabb_min[2], bits(first)));
-            nodes.push_back(f4(n.aabb_max[0], n.aabb_max[1], n.aabb_max[2], bits(RT_NODE_LEAF_BIT | n.triangle_count)));
+            ref = RT_REF_LEAF_BIT | (n.triangle_count << RT_REF_COUNT_SHIFT) | (uint32_t)first;
         } else {
-            nodes.push_back(f4(n.aabb_min[0], n.aabb_min[1], n.aabb_min[2], bits(0xFFFFFFFFu)));
-            nodes.push_back(f4(n.aabb_max[0], n.aabb_max[1], n.aabb_max[2], bits(0xFFFFFFFFu)));
-            stack.push_back({n.child_left, dev, false});
-            stack.push_back({n.child_right, dev, true});
-            if (stack.size() > max_sp) max_sp = stack.size();
+            if (!check_node(n.child_left) || !check_node(n.child_right))
+                return fail(RT_ERR_OUT_OF_RANGE, "mesh %u: node %u has a child outside the %u nodes", mesh_index, it.src,
+                            desc->n_mesh_bvh_nodes);
+            ref = (uint32_t)(nodes.size() / 4);
+            const RtBvhNode& l = desc->mesh_bvh_nodes[n.child_left];
+            const RtBvhNode& r = desc->mesh_bvh_nodes[n.child_right];
+            nodes.push_back(f4(l.aabb_min[0], l.aabb_min[1], l.aabb_min[2], l.aabb_max[0]));
+            nodes.push_back(f4(l.aabb_max[1], l.aabb_max[2], r.aabb_min[0], r.aabb_min[1]));
+            nodes.push_back(f4(r.aabb_min[2], r.aabb_max[0], r.aabb_max[1], r.aabb_max[2]));
+            nodes.push_back(f4(bits(RT_REF_NONE), bits(RT_REF_NONE), 0.0f, 0.0f));
+            stack.push_back({n.child_left, ref, false, it.depth + 1});
+            stack.push_back({n.child_right, ref, true, it.depth + 1});
+            // a depth-first walk in any child order holds at most one pending sibling per level
+            if (it.depth + 2 > need) need = it.depth + 2;
+        }
+        if (it.parent == 0xFFFFFFFFu) {
+            out->root_ref = ref;
+            memcpy(out->root_lo, n.aabb_min, 12);
+            memcpy(out->root_hi, n.aabb_max, 12);
+        } else {
+            float4& p = nodes[4 * (size_t)it.parent + 3];
+            if (it.right) p.y = bits(ref); else p.x = bits(ref);
         }
     }
-    out->stack_need = (uint32_t)max_sp;
+    out->stack_need = need;
     return RT_OK;
 }
 
@@ -229,9 +256,25 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device_id, RtScene**
         mat34(in.rotation_scale_inverse, &o.rotation_scale_inverse);
         mat34(in.model, &o.model);
         mat34(in.rotation_scale, &o.rotation_scale);
-        o.root = layouts[in.mesh].root;
+        const MeshLayout& ml = layouts[in.mesh];
+        memcpy(o.root_lo, ml.root_lo, 12);
+        memcpy(o.root_hi, ml.root_hi, 12);
+        o.root_ref = ml.root_ref;
         o.material_override = in.material_override;
-        if (layouts[in.mesh].stack_need > stack_entries) stack_entries = layouts[in.mesh].stack_need;
+        // Moeller-Trumbore's t carries a rounding error of at most about 10 eps K (t + D) / |a| with
+        // K = |e1||e2|, D = |e1|+|e2| and |a| >= 1e-5 (intersect.rs:152-153): below 2^-7 (t + D) for
+        // K <= 1/8, which the pruning slack of the kernel (2^-6 relative, 2^-5 D absolute) dominates.
+        o.prunable = (ml.max_edge_product <= 0.125f) ? 1u : 0u;
+        o.prune_abs = 0.03125f * ml.max_edge_sum;
+        // A hit's world position is model * (local point +- 1e-4 * unit normal) (intersect.rs:312-316,
+        // 379-385), so its world distance differs from (local t) / |rotation_scale_inverse * d| by at
+        // most 1e-4 * ||rotation_scale|| plus rounding; the Frobenius norm bounds the spectral norm.
+        double fro = 0.0;
+        for (int c = 0; c < 3; ++c)
+            for (int r = 0; r < 3; ++r) fro += (double)in.rotation_scale[4 * c + r] * in.rotation_scale[4 * c + r];
+        o.world_guard = (float)(1.5e-4 * std::sqrt(fro));
+        if (!(o.world_guard == o.world_guard) || o.world_guard > 1e30f) o.prunable = 0;
+        if (ml.stack_need > stack_entries) stack_entries = ml.stack_need;
     }
     if (stack_entries > RT_BVH_STACK_LEN)
         return fail(RT_ERR_BVH_TOO_DEEP, "a mesh BVH can need %u traversal stack entries; the reference's ArrayVec holds %d (intersect.rs:240)",

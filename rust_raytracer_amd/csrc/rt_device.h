@@ -50,11 +50,19 @@ struct DInstance {
     DMat34 rotation_scale_inverse;
     DMat34 model;
     DMat34 rotation_scale;
-    uint32_t root;              // device node index of the mesh root, 0xFFFFFFFF for an empty mesh
-    int32_t material_override;  // -1 = none
+    float root_lo[3], root_hi[3];   // AABB of the mesh's root node
+    uint32_t root_ref;              // child reference of the root (see DScene::nodes), RT_REF_NONE for an empty mesh
+    int32_t material_override;      // -1 = none
+    uint32_t prunable;              // 1: distance pruning and near-first ordering are provably result-preserving
+    float prune_abs;                // absolute slack (mesh-local units) added to every pruning comparison
+    float world_guard;              // bound on |t_world - k * t_local| for hits on this instance (world units)
 };
 
-#define RT_NODE_LEAF_BIT 0x80000000u
+// A child reference: inner node index, or a leaf given by its first triangle slot and its count.
+#define RT_REF_NONE 0xFFFFFFFFu
+#define RT_REF_LEAF_BIT 0x80000000u
+#define RT_REF_COUNT_SHIFT 28
+#define RT_REF_SLOT_MASK 0x0FFFFFFFu
 
 // Arrays in device memory.
 struct DScene {
@@ -67,12 +75,13 @@ struct DScene {
     const DSphere* spheres;
     const DTriangle* triangles;
     const DInstance* instances;
-    // node i: nodes[2*i] = (min.xyz, bits a), nodes[2*i+1] = (max.xyz, bits b)
-    //   inner: a = left child, b = right child        leaf: a = first triangle slot, b = RT_NODE_LEAF_BIT | count
+    // Inner node i is 64 B and holds the boxes of its two children, so one fetch decides both:
+    //   nodes[4*i]   = (L.min.x, L.min.y, L.min.z, L.max.x)   nodes[4*i+1] = (L.max.y, L.max.z, R.min.x, R.min.y)
+    //   nodes[4*i+2] = (R.min.z, R.max.x, R.max.y, R.max.z)   nodes[4*i+3] = (bits ref L, bits ref R, 0, 0)
     const float4* nodes;
-    // slot s: tri_hot[3*s] = (p0.xyz, e1.x), [3*s+1] = (e1.y, e1.z, e2.x, e2.y), [3*s+2] = (e2.z, bits mesh_triangle_index, bits material, 0)
+    // slot s: tri_hot[3*s] = (p0.xyz, e1.x), [3*s+1] = (e1.y, e1.z, e2.x, e2.y), [3*s+2] = (e2.z, fn.xyz)
     const float4* tri_hot;
-    // slot s: tri_cold[3*s] = (n0.xyz, fn.x), [3*s+1] = (n1.xyz, fn.y), [3*s+2] = (n2.xyz, fn.z)
+    // slot s: tri_cold[3*s] = (n0.xyz, bits mesh_triangle_index), [3*s+1] = (n1.xyz, bits material), [3*s+2] = (n2.xyz, 0)
     const float4* tri_cold;
 };
 

@@ -19,7 +19,8 @@
 //    (the shadow ray of raytracer.rs:78) - every trip round the loop traces exactly one ray through
 //    the same inlined scene traversal, whatever state the lane is in.
 //  * The BVH traversal stack of intersect.rs:240-256 is a per-lane column of LDS
-//    (stack[entry][lane], conflict-free), nodes are 32 B, leaf triangles are consecutive.
+//    (stack[entry][lane], conflict-free); an inner node is 64 B and carries the boxes of both
+//    children; the triangles of a leaf are consecutive.
 //
 // Every arithmetic expression that feeds a hit decision keeps the operation order of the reference
 // (see the citations at each function); the file must be compiled with -ffp-contract=off and
@@ -30,6 +31,7 @@
 
 #define RT_BLOCK_THREADS 256
 #define RT_WAVE 64
+#define RT_REFILL_CHUNK 64u
 
 namespace {
 
@@ -165,15 +167,59 @@ __device__ __forceinline__ Hitpoint triangle_hitpoint(const Ray& r, float t, flo
 // utils/mod.rs:13-24
 __device__ __forceinline__ bool closer(bool have, float best_t, float t) { return !have || t < best_t; }
 
-// Closest hit of `r` against the whole scene: scene.rs:120-140.  `stack` points at this lane's
-// column of the wave's LDS stack (stride RT_WAVE words).
-__device__ __forceinline__ void trace_scene(const DScene& S, const Ray& r, uint32_t* stack, Closest& best) {
+__device__ __forceinline__ bool finite1(float x) { return (x - x) == 0.0f; }
+__device__ __forceinline__ bool finite3(V3 a) { return finite1(a.x) && finite1(a.y) && finite1(a.z); }
+
+// AABB::intersect, intersect.rs:185-226, with the ray-only reciprocal hoisted (it is recomputed per
+// node there, from the same operands).  Also returns tmin.
+__device__ __forceinline__ bool slab(float lx, float ly, float lz, float hx, float hy, float hz, V3 o, V3 inv, float& tmin) {
+    float t1 = (lx - o.x) * inv.x;
+    float t2 = (hx - o.x) * inv.x;
+    float t3 = (ly - o.y) * inv.y;
+    float t4 = (hy - o.y) * inv.y;
+    float t5 = (lz - o.z) * inv.z;
+    float t6 = (hz - o.z) * inv.z;
+    tmin = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
+    float tmax = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
+    return !(tmax < 0.0f) && !(tmin > tmax);
+}
+
+#define RT_INF __uint_as_float(0x7F800000u)
+// Pruning slack, see trace_scene: relative part of every "is this box beyond the best hit" comparison.
+#define RT_PRUNE_REL 1.015625f            // 1 + 2^-6
+
+// Closest hit of `r` against the whole scene with the outcome of scene.rs:120-140.
+//
+// `stack` points at this lane's column of the wave's LDS stack: entry e of the reference column is
+// stack[e * RT_WAVE], its box-entry distance is stack[(entries + e) * RT_WAVE].
+//
+// Mesh traversal visits fewer nodes than intersect.rs:228-269 does, without changing the result:
+//  * A node's box is tested when its parent is visited (the parent holds both child boxes), with
+//    the reference's arithmetic, so the set of boxes that "pass" is the reference's.
+//  * Distance pruning: a box whose entry distance lies beyond the best candidate so far (or beyond
+//    `limit_world`: the best hit of earlier primitives, or the light of a shadow ray) by more than
+//    the slack cannot hold a candidate that compares lower.  The slack (RT_PRUNE_REL and the
+//    instance's prune_abs) dominates the rounding error of Moeller-Trumbore's t for the triangle
+//    sizes of a `prunable` mesh; other meshes are walked exactly as the reference walks them.
+//  * Near child first.  The reference resolves equal t by visiting order (utils/mod.rs:17, strict
+//    `<`); triangle slots are numbered in that visiting order, so "lower slot wins a tie" gives the
+//    same winner in any visiting order.
+//  * Rays with a non-finite component take the reference's order and no pruning; a NaN candidate
+//    ends the walk because nothing can replace it.
+// any_hit (shadow rays, raytracer.rs:171-187): the caller only needs `have && t < limit_world`
+// (or `have` for a directional light), so the walk stops at the first candidate that settles it.
+__device__ __forceinline__ void trace_scene(const DScene& S, const Ray& r, uint32_t* stack, Closest& best,
+                                            const float limit_world, const bool any_hit, const bool directional) {
     best.have = false;
     best.t = 0.0f;
     best.prim = RT_PRIM_NONE;
     best.inst = RT_INSTANCE_NONE;
     best.tl = best.u = best.v = 0.0f;
     best.slot = 0;
+    const bool ray_finite = finite3(r.o) && finite3(r.d);
+    // a shadow ray may stop as soon as one candidate proves "shadow"; with NaNs about only the
+    // directional case is decided by the mere existence of a candidate
+    const bool early = any_hit && (directional || ray_finite);
 
     // planes.as_slice().intersect(ray): intersect.rs:20-36 then the merge of scene.rs:129
     {
@@ -184,6 +230,7 @@ __device__ __forceinline__ void trace_scene(const DScene& S, const Ray& r, uint3
         }
         if (g_have && closer(best.have, best.t, g_t)) { best.have = true; best.t = g_t; best.prim = ((uint32_t)RT_PRIM_PLANE << 30) | g_i; }
     }
+    if (early && best.have && (directional || best.t < limit_world)) return;
     {
         bool g_have = false; float g_t = 0.0f; uint32_t g_i = 0;
         for (uint32_t i = 0; i < S.n_spheres; ++i) {
@@ -192,6 +239,7 @@ __device__ __forceinline__ void trace_scene(const DScene& S, const Ray& r, uint3
         }
         if (g_have && closer(best.have, best.t, g_t)) { best.have = true; best.t = g_t; best.prim = ((uint32_t)RT_PRIM_SPHERE << 30) | g_i; }
     }
+    if (early && best.have && (directional || best.t < limit_world)) return;
     {
         bool g_have = false; float g_t = 0.0f; uint32_t g_i = 0;
         for (uint32_t i = 0; i < S.n_triangles; ++i) {
@@ -203,57 +251,105 @@ __device__ __forceinline__ void trace_scene(const DScene& S, const Ray& r, uint3
         }
         if (g_have && closer(best.have, best.t, g_t)) { best.have = true; best.t = g_t; best.prim = ((uint32_t)RT_PRIM_TRIANGLE << 30) | g_i; }
     }
+    if (early && best.have && (directional || best.t < limit_world)) return;
+
+    uint32_t* stack_t = stack + S.stack_entries * RT_WAVE;
+    const float o_l1 = fabsf(r.o.x) + fabsf(r.o.y) + fabsf(r.o.z);
 
     // mesh instances in Vec order: intersect.rs:290-326 around 228-269
     for (uint32_t ii = 0; ii < S.n_instances; ++ii) {
         const DInstance& inst = S.instances[ii];
-        if (inst.root == 0xFFFFFFFFu) continue;                 // empty node range, intersect.rs:235-237
+        if (inst.root_ref == RT_REF_NONE) continue;             // empty node range, intersect.rs:235-237
+        if (best.have && best.t != best.t) break;               // a NaN closest hit is final (utils/mod.rs:17)
         Ray lr;
         lr.o = transform34(inst.model_inverse, r.o);
-        lr.d = normalize3(transform34(inst.rotation_scale_inverse, r.d));
-        // AABB::intersect recomputes 1/d per node (intersect.rs:190-195); it only depends on the ray
-        float ix = 1.0f / lr.d.x, iy = 1.0f / lr.d.y, iz = 1.0f / lr.d.z;
+        V3 dv = transform34(inst.rotation_scale_inverse, r.d);
+        float dn = sqrtf(dot3(dv, dv));
+        lr.d = mk(dv.x / dn, dv.y / dn, dv.z / dn);             // glm::normalize
+        V3 inv = mk(1.0f / lr.d.x, 1.0f / lr.d.y, 1.0f / lr.d.z);
+
+        const bool fast = inst.prunable && ray_finite && finite3(lr.o) && finite3(lr.d);
+        const float slack_w = 2.0f * inst.world_guard;
+        // mesh-local bound on useful t: a hit at world distance w lies at local t = w * dn (up to world_guard)
+        float limit = RT_INF;
+        if (fast) {
+            float lw = limit_world;
+            if (best.have && best.t < lw) lw = best.t;
+            if (lw < RT_INF) limit = (lw + slack_w + 1.52587890625e-05f * (o_l1 + lw)) * dn * 1.0009765625f;
+        }
+        const float prune_abs = inst.prune_abs;
+
+        float root_tmin;
+        if (!slab(inst.root_lo[0], inst.root_lo[1], inst.root_lo[2], inst.root_hi[0], inst.root_hi[1], inst.root_hi[2], lr.o, inv, root_tmin))
+            continue;
+        if (fast && root_tmin > limit * RT_PRUNE_REL + prune_abs) continue;
 
         bool m_have = false; float m_t = 0.0f, m_u = 0.0f, m_v = 0.0f; uint32_t m_slot = 0;
-        uint32_t sp = 0;
-        stack[0] = inst.root;
-        sp = 1;
+        bool settled = false;                                   // any_hit: the answer is known
+        uint32_t sp = 1;
+        stack[0] = inst.root_ref;
+        stack_t[0] = __float_as_uint(root_tmin);
         while (sp > 0) {
             --sp;
-            uint32_t n = stack[sp * RT_WAVE];
-            float4 lo = S.nodes[2 * n];
-            float4 hi = S.nodes[2 * n + 1];
-            // intersect.rs:200-221
-            float t1 = (lo.x - lr.o.x) * ix;
-            float t2 = (hi.x - lr.o.x) * ix;
-            float t3 = (lo.y - lr.o.y) * iy;
-            float t4 = (hi.y - lr.o.y) * iy;
-            float t5 = (lo.z - lr.o.z) * iz;
-            float t6 = (hi.z - lr.o.z) * iz;
-            float tmin = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
-            float tmax = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
-            if (tmax < 0.0f) continue;
-            if (tmin > tmax) continue;
-            uint32_t a = __float_as_uint(lo.w), b = __float_as_uint(hi.w);
-            if (!(b & RT_NODE_LEAF_BIT)) {
-                stack[sp * RT_WAVE] = a;             // child_left, then child_right: right is popped first
-                stack[(sp + 1) * RT_WAVE] = b;
-                sp += 2;
-            } else {
-                uint32_t cnt = b & 0xFFu;
+            const uint32_t ref = stack[sp * RT_WAVE];
+            const float entry = __uint_as_float(stack_t[sp * RT_WAVE]);
+            float cut = RT_INF;                                 // boxes entered beyond this cannot matter
+            if (fast) {
+                float lim = (m_have && m_t < limit) ? m_t : limit;
+                cut = lim * RT_PRUNE_REL + prune_abs;
+            }
+            if (entry > cut) continue;
+            if (ref & RT_REF_LEAF_BIT) {
+                const uint32_t first = ref & RT_REF_SLOT_MASK;
+                const uint32_t cnt = (ref >> RT_REF_COUNT_SHIFT) & 7u;
+                bool improved = false;
                 for (uint32_t k = 0; k < cnt; ++k) {
-                    uint32_t slot = a + k;
+                    const uint32_t slot = first + k;
                     float4 h0 = S.tri_hot[3 * slot];
                     float4 h1 = S.tri_hot[3 * slot + 1];
                     float4 h2 = S.tri_hot[3 * slot + 2];
                     float t, u, v;
                     if (triangle_tuv(mk(h0.x, h0.y, h0.z), mk(h0.w, h1.x, h1.y), mk(h1.z, h1.w, h2.x), lr, t, u, v) &&
-                        closer(m_have, m_t, t)) {
+                        (!m_have || t < m_t || (t == m_t && slot < m_slot))) {
                         m_have = true; m_t = t; m_u = u; m_v = v; m_slot = slot;
+                        improved = true;
                     }
                 }
+                if (m_have && m_t != m_t) sp = 0;               // NaN candidate: final
+                if (early && improved) {
+                    // would this candidate already prove "shadow"?  The instance's final hit has a local t
+                    // that is not larger, hence a world t that is at most 2 * world_guard larger.
+                    float4 h2 = S.tri_hot[3 * m_slot + 2];
+                    V3 fn = mk(h2.y, h2.z, h2.w);
+                    V3 p = lr.o + lr.d * m_t;
+                    V3 sn = (dot3(fn, lr.d) < 0.0f) ? fn : -fn;
+                    float tw = distance3(r.o, transform34(inst.model, p + sn * 1e-4f));
+                    if (directional || tw < limit_world - (slack_w + 6.103515625e-05f * (o_l1 + limit_world))) {
+                        best.have = true; best.t = tw;
+                        settled = true;
+                        sp = 0;
+                    }
+                }
+            } else {
+                const float4 n0 = S.nodes[4 * ref], n1 = S.nodes[4 * ref + 1], n2 = S.nodes[4 * ref + 2], n3 = S.nodes[4 * ref + 3];
+                float tl, tr;
+                bool hl = slab(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, lr.o, inv, tl);
+                bool hr = slab(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, lr.o, inv, tr);
+                hl = hl && !(tl > cut);
+                hr = hr && !(tr > cut);
+                uint32_t rl = __float_as_uint(n3.x), rr = __float_as_uint(n3.y);
+                // reference order: push left, push right, so that right is popped first (intersect.rs:253-256);
+                // on the fast path the nearer child is popped first instead
+                if (fast && tl < tr) {
+                    uint32_t tu = rl; rl = rr; rr = tu;
+                    float tf = tl; tl = tr; tr = tf;
+                    bool tb = hl; hl = hr; hr = tb;
+                }
+                if (hl) { stack[sp * RT_WAVE] = rl; stack_t[sp * RT_WAVE] = __float_as_uint(tl); ++sp; }
+                if (hr) { stack[sp * RT_WAVE] = rr; stack_t[sp * RT_WAVE] = __float_as_uint(tr); ++sp; }
             }
         }
+        if (settled) return;
         if (m_have) {
             // world-space t of this instance's closest hit: intersect.rs:312-319
             float4 h2 = S.tri_hot[3 * m_slot + 2];
@@ -269,6 +365,7 @@ __device__ __forceinline__ void trace_scene(const DScene& S, const Ray& r, uint3
                 best.tl = m_t; best.u = m_u; best.v = m_v;
                 best.prim = ((uint32_t)RT_PRIM_MESH_TRIANGLE << 30) | __float_as_uint(S.tri_cold[3 * m_slot].w);
             }
+            if (early && best.have && (directional || best.t < limit_world)) return;
         }
     }
 }
@@ -419,7 +516,7 @@ rt_trace_level(const DScene S, const DFrame F, const uint32_t level) {
     extern __shared__ uint32_t lds_stack[];
     const uint32_t lane = threadIdx.x & (RT_WAVE - 1);
     const uint32_t wave = threadIdx.x / RT_WAVE;
-    uint32_t* stack = lds_stack + wave * (S.stack_entries * RT_WAVE) + lane;
+    uint32_t* stack = lds_stack + wave * (2 * S.stack_entries * RT_WAVE) + lane;
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
 
     DCounters* C = F.counters;
@@ -436,6 +533,9 @@ rt_trace_level(const DScene S, const DFrame F, const uint32_t level) {
     uint32_t spill_n = 0;
 
     uint32_t n_primary = 0, n_shadow = 0, n_reflected = 0, n_transmitted = 0, n_spilled = 0;
+
+    uint32_t chunk_next = 0, chunk_end = 0;     // wave-uniform: the input indices this wave has reserved
+    bool exhausted = false;
 
     int state = ST_IDLE;
     RayRec cur;                 // the lane's MAIN ray
@@ -460,16 +560,24 @@ rt_trace_level(const DScene S, const DFrame F, const uint32_t level) {
             state = ST_MAIN;
         }
         {
+            // The wave reserves RT_REFILL_CHUNK consecutive input indices with one atomic and hands them
+            // to its idle lanes over the following trips: one contended atomic per chunk, not per trip.
             bool want = state == ST_IDLE;
             unsigned long long mask = __ballot(want);
             if (mask) {
-                uint32_t leader = __ffsll((long long)mask) - 1;
-                uint32_t base = 0;
-                if (lane == leader) base = atomicAdd(&C->cursor, (unsigned int)__popcll(mask));
-                base = __shfl(base, leader);
+                if (chunk_next == chunk_end && !exhausted) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&C->cursor, (unsigned int)RT_REFILL_CHUNK);
+                    base = __shfl(base, 0);
+                    if (base >= n_in) exhausted = true;
+                    else { chunk_next = base; chunk_end = (n_in - base < RT_REFILL_CHUNK) ? n_in : base + RT_REFILL_CHUNK; }
+                }
+                const uint32_t avail = chunk_end - chunk_next;
+                const uint32_t asking = __popcll(mask);
                 if (want) {
-                    uint32_t idx = base + __popcll(mask & ((1ull << lane) - 1ull));
-                    if (idx < n_in) {
+                    uint32_t r = __popcll(mask & ((1ull << lane) - 1ull));
+                    if (r < avail) {
+                        uint32_t idx = chunk_next + r;
                         if (level == 0) {
                             uint32_t col, row;
                             if (pixel_coords(F, idx, col, row)) {
@@ -482,10 +590,11 @@ rt_trace_level(const DScene S, const DFrame F, const uint32_t level) {
                             cur = load_rec(q_in, idx);
                             state = ST_MAIN;
                         }
-                    } else {
+                    } else if (exhausted && avail == 0) {
                         state = ST_EMPTY;
                     }
                 }
+                chunk_next += asking < avail ? asking : avail;
             }
         }
         if (__all(state == ST_EMPTY)) break;
@@ -495,8 +604,15 @@ rt_trace_level(const DScene S, const DFrame F, const uint32_t level) {
         cl.have = false;
         {
             Ray tr = cur.ray;
-            if (state == ST_SHADOW) tr = sray;
-            if (state == ST_MAIN || state == ST_SHADOW) trace_scene(S, tr, stack, cl);
+            float limit_world = RT_INF;
+            bool directional = false;
+            if (state == ST_SHADOW) {
+                tr = sray;
+                const DLight& L = S.lights[light_i];
+                directional = L.pos[3] == 0.0f;
+                if (!directional) limit_world = distance3(sray.o, ld3(L.world));      // raytracer.rs:177-178
+            }
+            if (state == ST_MAIN || state == ST_SHADOW) trace_scene(S, tr, stack, cl, limit_world, state == ST_SHADOW, directional);
         }
         // children produced by this trip round the loop; queued together further down
         bool emit_r = false, emit_t = false;
@@ -733,7 +849,8 @@ __global__ void rt_assemble(const uint8_t* gathered, uint8_t* frame, uint32_t wi
 // ---- launch wrappers (called from rt_api.hip) ----------------------------------------------------
 
 static size_t trace_lds_bytes(uint32_t stack_entries) {
-    return (size_t)(RT_BLOCK_THREADS / RT_WAVE) * stack_entries * RT_WAVE * sizeof(uint32_t);
+    // two words per stack entry (child reference, box entry distance), one column per lane
+    return (size_t)(RT_BLOCK_THREADS / RT_WAVE) * 2 * stack_entries * RT_WAVE * sizeof(uint32_t);
 }
 
 // Resident blocks of the trace kernel per compute unit (registers and the LDS stacks decide).
