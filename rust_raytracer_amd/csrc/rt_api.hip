@@ -557,6 +557,17 @@ extern "C" int rt_debug_last_spilled(RtScene* s, uint32_t* out) {
     return RT_OK;
 }
 
+#ifdef RT_STATS
+extern "C" int rt_debug_stats(RtScene* s, unsigned long long* out /* [64][7] */) {
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->last_stream));
+    DCounters c;
+    HIP_TRY(hipMemcpy(&c, s->f.counters, sizeof(c), hipMemcpyDeviceToHost));
+    memcpy(out, c.dbg, sizeof(c.dbg));
+    return RT_OK;
+}
+#endif
+
 extern "C" const char* rt_last_error(void) { return g_error; }
 
 // shared with host/rt_host.cpp so that both halves of the library report through rt_last_error()

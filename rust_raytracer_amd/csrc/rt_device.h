@@ -91,6 +91,11 @@ struct DCounters {
     unsigned int queue_count[2];     // rays appended to each of the two queues (may exceed capacity)
     unsigned int cursor;             // next input index handed out in the running pass
     unsigned int spilled;            // children that did not fit the queue and were traced by their parent lane
+#ifdef RT_STATS
+    // diagnostic build only, per depth: inner nodes visited, leaves visited, triangles tested, instance
+    // set-ups, traversal loop trips (per wave), lane transitions, outer loop trips (per wave)
+    unsigned long long dbg[64][7];
+#endif
 };
 
 struct DFrame {

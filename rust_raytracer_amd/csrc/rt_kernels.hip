@@ -185,6 +185,14 @@ __device__ __forceinline__ bool slab(float lx, float ly, float lz, float hx, flo
 }
 
 #define RT_INF __uint_as_float(0x7F800000u)
+
+// Diagnostic build (-DRT_STATS): per-launch totals of traversal events, see DCounters::dbg.
+#ifdef RT_STATS
+struct DbgStats { uint32_t inner, leaf, tris, setups, rounds, transitions; };
+#define RT_STAT(x) (x)
+#else
+#define RT_STAT(x) ((void)0)
+#endif
 // Pruning slack, see trace_scene: relative part of every "is this box beyond the best hit" comparison.
 #define RT_PRUNE_REL 1.015625f            // 1 + 2^-6
 
@@ -209,7 +217,11 @@ __device__ __forceinline__ bool slab(float lx, float ly, float lz, float hx, flo
 // any_hit (shadow rays, raytracer.rs:171-187): the caller only needs `have && t < limit_world`
 // (or `have` for a directional light), so the walk stops at the first candidate that settles it.
 __device__ __forceinline__ void trace_scene(const DScene& S, const Ray& r, uint32_t* stack, Closest& best,
-                                            const float limit_world, const bool any_hit, const bool directional) {
+                                            const float limit_world, const bool any_hit, const bool directional
+#ifdef RT_STATS
+                                            , DbgStats& dbg
+#endif
+                                            ) {
     best.have = false;
     best.t = 0.0f;
     best.prim = RT_PRIM_NONE;
@@ -256,40 +268,85 @@ __device__ __forceinline__ void trace_scene(const DScene& S, const Ray& r, uint3
     uint32_t* stack_t = stack + S.stack_entries * RT_WAVE;
     const float o_l1 = fabsf(r.o.x) + fabsf(r.o.y) + fabsf(r.o.z);
 
-    // mesh instances in Vec order: intersect.rs:290-326 around 228-269
-    for (uint32_t ii = 0; ii < S.n_instances; ++ii) {
-        const DInstance& inst = S.instances[ii];
-        if (inst.root_ref == RT_REF_NONE) continue;             // empty node range, intersect.rs:235-237
-        if (best.have && best.t != best.t) break;               // a NaN closest hit is final (utils/mod.rs:17)
-        Ray lr;
-        lr.o = transform34(inst.model_inverse, r.o);
-        V3 dv = transform34(inst.rotation_scale_inverse, r.d);
-        float dn = sqrtf(dot3(dv, dv));
-        lr.d = mk(dv.x / dn, dv.y / dn, dv.z / dn);             // glm::normalize
-        V3 inv = mk(1.0f / lr.d.x, 1.0f / lr.d.y, 1.0f / lr.d.z);
+    // Mesh instances in Vec order: intersect.rs:290-326 around 228-269.  Every lane walks its own
+    // sequence instance 0, 1, ... and steps through one BVH node per trip of the loop below, so a lane
+    // that is done with an instance does not wait for the lanes still inside it.  Entering and leaving
+    // an instance (transforms, root test, world-space t) is the expensive, divergent part: lanes that
+    // need it wait until a quarter of the wave does, or until no lane has a node left to visit.
+    uint32_t next_inst = 0, cur_inst = 0;
+    bool in_mesh = false, done = false;
+    uint32_t sp = 0;
+    Ray lr;
+    lr.o = lr.d = mk(0, 0, 0);
+    V3 inv = mk(0, 0, 0);
+    bool fast = false;
+    float limit = RT_INF, prune_abs = 0.0f, slack_w = 0.0f;
+    bool m_have = false; float m_t = 0.0f, m_u = 0.0f, m_v = 0.0f; uint32_t m_slot = 0;
 
-        const bool fast = inst.prunable && ray_finite && finite3(lr.o) && finite3(lr.d);
-        const float slack_w = 2.0f * inst.world_guard;
-        // mesh-local bound on useful t: a hit at world distance w lies at local t = w * dn (up to world_guard)
-        float limit = RT_INF;
-        if (fast) {
-            float lw = limit_world;
-            if (best.have && best.t < lw) lw = best.t;
-            if (lw < RT_INF) limit = (lw + slack_w + 1.52587890625e-05f * (o_l1 + lw)) * dn * 1.0009765625f;
+    for (;;) {
+        const bool waiting = !done && sp == 0;
+        const unsigned long long wait_mask = __ballot(waiting);
+        const unsigned long long run_mask = __ballot(!done && sp > 0);
+        if (!wait_mask && !run_mask) break;
+        RT_STAT(dbg.rounds += (__ffsll((long long)(wait_mask | run_mask)) - 1 == (int)(threadIdx.x & 63)) ? 1u : 0u);
+        if (waiting && (run_mask == 0 || __popcll(wait_mask) >= 16)) {
+            RT_STAT(dbg.transitions += 1);
+            if (in_mesh) {
+                in_mesh = false;
+                if (m_have) {
+                    // world-space t of this instance's closest hit: intersect.rs:312-319
+                    const DInstance& inst = S.instances[cur_inst];
+                    float4 h2 = S.tri_hot[3 * m_slot + 2];
+                    V3 fn = mk(h2.y, h2.z, h2.w);
+                    V3 p = lr.o + lr.d * m_t;
+                    bool front = dot3(fn, lr.d) < 0.0f;
+                    V3 sn = front ? fn : -fn;
+                    V3 pos_local = p + sn * 1e-4f;
+                    V3 pos_world = transform34(inst.model, pos_local);
+                    float tw = distance3(r.o, pos_world);
+                    if (closer(best.have, best.t, tw)) {
+                        best.have = true; best.t = tw; best.inst = cur_inst; best.slot = m_slot;
+                        best.tl = m_t; best.u = m_u; best.v = m_v;
+                        best.prim = ((uint32_t)RT_PRIM_MESH_TRIANGLE << 30) | __float_as_uint(S.tri_cold[3 * m_slot].w);
+                    }
+                    if (early && best.have && (directional || best.t < limit_world)) done = true;
+                }
+            }
+            if (best.have && best.t != best.t) done = true;     // a NaN closest hit is final (utils/mod.rs:17)
+            while (!done && !in_mesh && next_inst < S.n_instances) {
+                const uint32_t ii = next_inst++;
+                RT_STAT(dbg.setups += 1);
+                const DInstance& inst = S.instances[ii];
+                if (inst.root_ref == RT_REF_NONE) continue;     // empty node range, intersect.rs:235-237
+                lr.o = transform34(inst.model_inverse, r.o);
+                V3 dv = transform34(inst.rotation_scale_inverse, r.d);
+                float dn = sqrtf(dot3(dv, dv));
+                lr.d = mk(dv.x / dn, dv.y / dn, dv.z / dn);     // glm::normalize
+                inv = mk(1.0f / lr.d.x, 1.0f / lr.d.y, 1.0f / lr.d.z);
+                fast = inst.prunable && ray_finite && finite3(lr.o) && finite3(lr.d);
+                slack_w = 2.0f * inst.world_guard;
+                // mesh-local bound on useful t: a hit at world distance w lies at local t = w * dn (up to world_guard)
+                limit = RT_INF;
+                if (fast) {
+                    float lw = limit_world;
+                    if (best.have && best.t < lw) lw = best.t;
+                    if (lw < RT_INF) limit = (lw + slack_w + 1.52587890625e-05f * (o_l1 + lw)) * dn * 1.0009765625f;
+                }
+                prune_abs = inst.prune_abs;
+                float root_tmin;
+                if (!slab(inst.root_lo[0], inst.root_lo[1], inst.root_lo[2], inst.root_hi[0], inst.root_hi[1], inst.root_hi[2], lr.o, inv, root_tmin))
+                    continue;
+                if (fast && root_tmin > limit * RT_PRUNE_REL + prune_abs) continue;
+                m_have = false; m_t = 0.0f; m_u = 0.0f; m_v = 0.0f; m_slot = 0;
+                stack[0] = inst.root_ref;
+                stack_t[0] = __float_as_uint(root_tmin);
+                sp = 1;
+                cur_inst = ii;
+                in_mesh = true;
+            }
+            if (!in_mesh) done = true;
         }
-        const float prune_abs = inst.prune_abs;
-
-        float root_tmin;
-        if (!slab(inst.root_lo[0], inst.root_lo[1], inst.root_lo[2], inst.root_hi[0], inst.root_hi[1], inst.root_hi[2], lr.o, inv, root_tmin))
-            continue;
-        if (fast && root_tmin > limit * RT_PRUNE_REL + prune_abs) continue;
-
-        bool m_have = false; float m_t = 0.0f, m_u = 0.0f, m_v = 0.0f; uint32_t m_slot = 0;
-        bool settled = false;                                   // any_hit: the answer is known
-        uint32_t sp = 1;
-        stack[0] = inst.root_ref;
-        stack_t[0] = __float_as_uint(root_tmin);
-        while (sp > 0) {
+        if (!done && sp > 0) {
             --sp;
             const uint32_t ref = stack[sp * RT_WAVE];
             const float entry = __uint_as_float(stack_t[sp * RT_WAVE]);
@@ -303,6 +360,8 @@ __device__ __forceinline__ void trace_scene(const DScene& S, const Ray& r, uint3
                 const uint32_t first = ref & RT_REF_SLOT_MASK;
                 const uint32_t cnt = (ref >> RT_REF_COUNT_SHIFT) & 7u;
                 bool improved = false;
+                RT_STAT(dbg.leaf += 1);
+                RT_STAT(dbg.tris += cnt);
                 for (uint32_t k = 0; k < cnt; ++k) {
                     const uint32_t slot = first + k;
                     float4 h0 = S.tri_hot[3 * slot];
@@ -319,6 +378,7 @@ __device__ __forceinline__ void trace_scene(const DScene& S, const Ray& r, uint3
                 if (early && improved) {
                     // would this candidate already prove "shadow"?  The instance's final hit has a local t
                     // that is not larger, hence a world t that is at most 2 * world_guard larger.
+                    const DInstance& inst = S.instances[cur_inst];
                     float4 h2 = S.tri_hot[3 * m_slot + 2];
                     V3 fn = mk(h2.y, h2.z, h2.w);
                     V3 p = lr.o + lr.d * m_t;
@@ -326,11 +386,12 @@ __device__ __forceinline__ void trace_scene(const DScene& S, const Ray& r, uint3
                     float tw = distance3(r.o, transform34(inst.model, p + sn * 1e-4f));
                     if (directional || tw < limit_world - (slack_w + 6.103515625e-05f * (o_l1 + limit_world))) {
                         best.have = true; best.t = tw;
-                        settled = true;
+                        done = true;
                         sp = 0;
                     }
                 }
             } else {
+                RT_STAT(dbg.inner += 1);
                 const float4 n0 = S.nodes[4 * ref], n1 = S.nodes[4 * ref + 1], n2 = S.nodes[4 * ref + 2], n3 = S.nodes[4 * ref + 3];
                 float tl, tr;
                 bool hl = slab(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, lr.o, inv, tl);
@@ -348,24 +409,6 @@ __device__ __forceinline__ void trace_scene(const DScene& S, const Ray& r, uint3
                 if (hl) { stack[sp * RT_WAVE] = rl; stack_t[sp * RT_WAVE] = __float_as_uint(tl); ++sp; }
                 if (hr) { stack[sp * RT_WAVE] = rr; stack_t[sp * RT_WAVE] = __float_as_uint(tr); ++sp; }
             }
-        }
-        if (settled) return;
-        if (m_have) {
-            // world-space t of this instance's closest hit: intersect.rs:312-319
-            float4 h2 = S.tri_hot[3 * m_slot + 2];
-            V3 fn = mk(h2.y, h2.z, h2.w);
-            V3 p = lr.o + lr.d * m_t;
-            bool front = dot3(fn, lr.d) < 0.0f;
-            V3 sn = front ? fn : -fn;
-            V3 pos_local = p + sn * 1e-4f;
-            V3 pos_world = transform34(inst.model, pos_local);
-            float tw = distance3(r.o, pos_world);
-            if (closer(best.have, best.t, tw)) {
-                best.have = true; best.t = tw; best.inst = ii; best.slot = m_slot;
-                best.tl = m_t; best.u = m_u; best.v = m_v;
-                best.prim = ((uint32_t)RT_PRIM_MESH_TRIANGLE << 30) | __float_as_uint(S.tri_cold[3 * m_slot].w);
-            }
-            if (early && best.have && (directional || best.t < limit_world)) return;
         }
     }
 }
@@ -438,6 +481,9 @@ __device__ __forceinline__ float fresnel_reflection(V3 refl_d, V3 trans_d, V3 N,
 
 __device__ __forceinline__ void add_channel(const DFrame& F, uint32_t pixel, int c, float v) {
     if (v == 0.0f) return;
+#ifdef RT_ABLATE_ATOMICS
+    if (v != 12345.678f) return;      // timing experiment only: results are wrong
+#endif
     if (fabsf(v) < RT_FIXED_LIMIT) {
         long long q = __double2ll_rn((double)v * RT_FIXED_ONE);
         atomicAdd(reinterpret_cast<unsigned long long*>(F.acc + (size_t)c * F.n_pixels + pixel), (unsigned long long)q);
@@ -537,6 +583,10 @@ rt_trace_level(const DScene S, const DFrame F, const uint32_t level) {
     uint32_t chunk_next = 0, chunk_end = 0;     // wave-uniform: the input indices this wave has reserved
     bool exhausted = false;
 
+#ifdef RT_STATS
+    DbgStats dbg = {0, 0, 0, 0, 0, 0};
+    uint32_t dbg_iters = 0;
+#endif
     int state = ST_IDLE;
     RayRec cur;                 // the lane's MAIN ray
     cur.ray.o = cur.ray.d = mk(0, 0, 0);
@@ -598,6 +648,7 @@ rt_trace_level(const DScene S, const DFrame F, const uint32_t level) {
             }
         }
         if (__all(state == ST_EMPTY)) break;
+        RT_STAT(dbg_iters += (lane == 0) ? 1u : 0u);
 
         // ---- trace one ray per busy lane -------------------------------------------------------
         Closest cl;
@@ -612,7 +663,11 @@ rt_trace_level(const DScene S, const DFrame F, const uint32_t level) {
                 directional = L.pos[3] == 0.0f;
                 if (!directional) limit_world = distance3(sray.o, ld3(L.world));      // raytracer.rs:177-178
             }
-            if (state == ST_MAIN || state == ST_SHADOW) trace_scene(S, tr, stack, cl, limit_world, state == ST_SHADOW, directional);
+            if (state == ST_MAIN || state == ST_SHADOW) trace_scene(S, tr, stack, cl, limit_world, state == ST_SHADOW, directional
+#ifdef RT_STATS
+                                                                    , dbg
+#endif
+                                                                    );
         }
         // children produced by this trip round the loop; queued together further down
         bool emit_r = false, emit_t = false;
@@ -767,13 +822,25 @@ rt_trace_level(const DScene S, const DFrame F, const uint32_t level) {
     for (int k = 0; k < 5; ++k) {
         uint32_t v = vals[k];
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+#ifndef RT_ABLATE_STATS
         if (lane == 0 && v) atomicAdd(&C->rays[k], (unsigned long long)v);
+#endif
     }
     {
         uint32_t v = n_spilled;
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
         if (lane == 0 && v) atomicAdd(&C->spilled, v);
     }
+#ifdef RT_STATS
+    {
+        uint32_t dv[7] = {dbg.inner, dbg.leaf, dbg.tris, dbg.setups, dbg.rounds, dbg.transitions, dbg_iters};
+        for (int k = 0; k < 7; ++k) {
+            uint32_t v = dv[k];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+            if (lane == 0 && v) atomicAdd(&C->dbg[level][k], (unsigned long long)v);
+        }
+    }
+#endif
 }
 
 // Clears the cursor between passes and resets the queue that the next pass will fill.
