@@ -385,7 +385,8 @@ static int ensure_frame(RtScene* s, const Geometry& g, uint32_t max_depth, bool 
         int rc;
         if ((rc = frame_alloc(s, (size_t)3 * g.n_pixels, &f.acc)) || (rc = frame_alloc(s, g.n_pixels, &f.poison)) ||
             (rc = frame_alloc(s, (size_t)2 * capacity, &f.queue[0])) || (rc = frame_alloc(s, (size_t)2 * capacity, &f.queue[1])) ||
-            (rc = frame_alloc(s, (size_t)blocks * 256 * max_depth * 2, &f.spill)) || (rc = frame_alloc(s, 1, &f.counters)))
+            (rc = frame_alloc(s, (size_t)blocks * 256 * max_depth * 2, &f.spill)) || (rc = frame_alloc(s, 1, &f.counters)) ||
+            (rc = frame_alloc(s, (size_t)blocks * 4 * 512 * 2, &f.staging)) || (rc = frame_alloc(s, (size_t)blocks * 4 * 8, &f.wave_stats)))
             return rc;
         if (aux && ((rc = frame_alloc(s, g.n_pixels, &f.aux_flags)) || (rc = frame_alloc(s, g.n_pixels, &f.aux_prim)) ||
                     (rc = frame_alloc(s, g.n_pixels, &f.aux_inst))))
@@ -421,6 +422,7 @@ static int enqueue_frame(RtScene* s, const RtRenderParams* p, bool sharded, bool
     HIP_TRY(hipMemsetAsync(f.acc, 0, (size_t)3 * g.n_pixels * sizeof(long long), stream));
     HIP_TRY(hipMemsetAsync(f.poison, 0, (size_t)g.n_pixels * sizeof(unsigned int), stream));
     HIP_TRY(hipMemsetAsync(f.counters, 0, sizeof(DCounters), stream));
+    HIP_TRY(hipMemsetAsync(f.wave_stats, 0, (size_t)blocks * 4 * 8 * sizeof(unsigned int), stream));
     if (aux) HIP_TRY(hipMemsetAsync(f.aux_flags, 0, (size_t)g.n_pixels * sizeof(unsigned int), stream));
     HIP_TRY(hipEventRecord(s->ev_trace_start, stream));
     for (uint32_t level = 0; level < max_depth; ++level) {
@@ -508,15 +510,25 @@ extern "C" int rt_assemble_shards(RtScene* s, const RtRenderParams* p, const voi
     return RT_OK;
 }
 
+static int sum_wave_stats(RtScene* s, uint64_t sums[8]) {
+    size_t n = (size_t)s->key.blocks * 4 * 8;
+    std::vector<unsigned int> host(n);
+    HIP_TRY(hipMemcpy(host.data(), s->f.wave_stats, n * sizeof(unsigned int), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 8; ++k) sums[k] = 0;
+    for (size_t i = 0; i < n; ++i) sums[i % 8] += host[i];
+    return RT_OK;
+}
+
 extern "C" int rt_last_ray_counts(RtScene* s, uint64_t counters[RT_N_COUNTERS]) {
     if (!s || !counters) return fail(RT_ERR_INVALID_ARGUMENT, "rt_last_ray_counts: null argument");
     if (!s->timed) return fail(RT_ERR_INVALID_ARGUMENT, "nothing has been rendered on this handle yet");
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipStreamSynchronize(s->last_stream));
-    DCounters c;
-    HIP_TRY(hipMemcpy(&c, s->f.counters, sizeof(c), hipMemcpyDeviceToHost));
+    uint64_t sums[8];
+    int rc = sum_wave_stats(s, sums);
+    if (rc) return rc;
     for (int k = 0; k < RT_N_COUNTERS; ++k) counters[k] = 0;
-    for (int k = 0; k < 5; ++k) counters[k] = c.rays[k];
+    for (int k = 0; k < 5; ++k) counters[k] = sums[k];
     return RT_OK;
 }
 
@@ -551,9 +563,10 @@ extern "C" int rt_debug_last_spilled(RtScene* s, uint32_t* out) {
     if (!s->timed) return fail(RT_ERR_INVALID_ARGUMENT, "nothing has been rendered on this handle yet");
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipStreamSynchronize(s->last_stream));
-    DCounters c;
-    HIP_TRY(hipMemcpy(&c, s->f.counters, sizeof(c), hipMemcpyDeviceToHost));
-    *out = c.spilled;
+    uint64_t sums[8];
+    int rc = sum_wave_stats(s, sums);
+    if (rc) return rc;
+    *out = (uint32_t)sums[5];
     return RT_OK;
 }
 

@@ -87,10 +87,7 @@ struct DScene {
 
 // Per-frame device state.
 struct DCounters {
-    unsigned long long rays[5];      // RT_CTR_RAYS .. RT_CTR_TRANSMITTED
     unsigned int queue_count[2];     // rays appended to each of the two queues (may exceed capacity)
-    unsigned int cursor;             // next input index handed out in the running pass
-    unsigned int spilled;            // children that did not fit the queue and were traced by their parent lane
 #ifdef RT_STATS
     // diagnostic build only, per depth: inner nodes visited, leaves visited, triangles tested, instance
     // set-ups, traversal loop trips (per wave), lane transitions, outer loop trips (per wave)
@@ -114,5 +111,7 @@ struct DFrame {
     unsigned int* aux_inst;          // [n_pixels] or null
     float4* queue[2];                // ray records, 2 float4 each
     float4* spill;                   // [threads][max_depth][2]
+    float4* staging;                 // [waves][512][2] children waiting to be moved to a queue
+    unsigned int* wave_stats;        // [waves][8]: rays, primary, shadow, reflected, transmitted, kept-by-parent
     DCounters* counters;
 };

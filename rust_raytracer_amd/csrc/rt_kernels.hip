@@ -32,6 +32,7 @@
 #define RT_BLOCK_THREADS 256
 #define RT_WAVE 64
 #define RT_REFILL_CHUNK 64u
+#define RT_STAGING_RECORDS 512u
 
 namespace {
 
@@ -553,6 +554,39 @@ __device__ __forceinline__ Ray primary_ray(const DFrame& F, uint32_t col, uint32
 
 enum { ST_IDLE = 0, ST_MAIN = 1, ST_SHADOW = 2, ST_EMPTY = 3 };
 
+// Moves a wave's staged ray records to the output queue: one atomic reserves the space, the lanes copy.
+// Records beyond the queue's capacity stay (moved to the front of the staging buffer) and `queue_full`
+// is set.  Must be called by all 64 lanes.
+__device__ __forceinline__ void flush_staging(DCounters* C, uint32_t level, uint32_t capacity, float4* q_out, float4* staging,
+                                              uint32_t& stage_n, bool& queue_full, uint32_t lane) {
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&C->queue_count[level & 1], stage_n);
+    base = __shfl(base, 0);
+    uint32_t fit = 0;
+    if (base < capacity) fit = (capacity - base < stage_n) ? capacity - base : stage_n;
+    for (uint32_t i = lane; i < fit; i += RT_WAVE) {
+        float4 a = staging[2 * (size_t)i], b = staging[2 * (size_t)i + 1];
+        q_out[2 * ((size_t)base + i)] = a;
+        q_out[2 * ((size_t)base + i) + 1] = b;
+    }
+    if (fit < stage_n) {
+        queue_full = true;
+        const uint32_t rest = stage_n - fit;
+        if (fit > 0) {
+            for (uint32_t i0 = 0; i0 < rest; i0 += RT_WAVE) {       // ascending: a pass never overwrites a later pass's source
+                uint32_t i = i0 + lane;
+                float4 a = make_float4(0, 0, 0, 0), b = a;
+                if (i < rest) { a = staging[2 * (size_t)(fit + i)]; b = staging[2 * (size_t)(fit + i) + 1]; }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                if (i < rest) { staging[2 * (size_t)i] = a; staging[2 * (size_t)i + 1] = b; }
+            }
+        }
+        stage_n = rest;
+    } else {
+        stage_n = 0;
+    }
+}
+
 }  // namespace
 
 // One pass over the rays of one recursion depth.  `level` 0 generates primary rays from pixel
@@ -580,8 +614,20 @@ rt_trace_level(const DScene S, const DFrame F, const uint32_t level) {
 
     uint32_t n_primary = 0, n_shadow = 0, n_reflected = 0, n_transmitted = 0, n_spilled = 0;
 
-    uint32_t chunk_next = 0, chunk_end = 0;     // wave-uniform: the input indices this wave has reserved
+    // Input: chunk c is the rays [c * RT_REFILL_CHUNK, (c + 1) * RT_REFILL_CHUNK); wave w of W takes the
+    // chunks w, w + W, w + 2W, ... - neighbouring chunks go to different waves, and nobody touches a
+    // shared cursor (a contended device-wide atomic costs about 10 ns, serialised over all waves).
+    const uint32_t gwave = gtid / RT_WAVE;
+    const uint32_t n_waves = gridDim.x * (RT_BLOCK_THREADS / RT_WAVE);
+    uint32_t my_chunk = gwave;
+    uint32_t chunk_next = 0, chunk_end = 0;     // wave-uniform: what is left of the current chunk
     bool exhausted = false;
+
+    // Output: children are staged in a wave-private buffer and moved to the next depth's queue in
+    // bulk, one atomic per move.  If that queue is full the wave keeps them and traces them itself.
+    float4* staging = F.staging + (size_t)gwave * RT_STAGING_RECORDS * 2;
+    uint32_t stage_n = 0;                       // wave-uniform
+    bool queue_full = false;                    // wave-uniform
 
 #ifdef RT_STATS
     DbgStats dbg = {0, 0, 0, 0, 0, 0};
@@ -610,44 +656,62 @@ rt_trace_level(const DScene S, const DFrame F, const uint32_t level) {
             state = ST_MAIN;
         }
         {
-            // The wave reserves RT_REFILL_CHUNK consecutive input indices with one atomic and hands them
-            // to its idle lanes over the following trips: one contended atomic per chunk, not per trip.
             bool want = state == ST_IDLE;
             unsigned long long mask = __ballot(want);
             if (mask) {
-                if (chunk_next == chunk_end && !exhausted) {
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(&C->cursor, (unsigned int)RT_REFILL_CHUNK);
-                    base = __shfl(base, 0);
-                    if (base >= n_in) exhausted = true;
-                    else { chunk_next = base; chunk_end = (n_in - base < RT_REFILL_CHUNK) ? n_in : base + RT_REFILL_CHUNK; }
-                }
-                const uint32_t avail = chunk_end - chunk_next;
                 const uint32_t asking = __popcll(mask);
-                if (want) {
-                    uint32_t r = __popcll(mask & ((1ull << lane) - 1ull));
-                    if (r < avail) {
-                        uint32_t idx = chunk_next + r;
-                        if (level == 0) {
-                            uint32_t col, row;
-                            if (pixel_coords(F, idx, col, row)) {
-                                cur.ray = primary_ray(F, col, row);
-                                cur.throughput = 1.0f;
-                                cur.meta = idx;
-                                state = ST_MAIN;
-                            }                                   // padding pixel: stay idle, ask again
-                        } else {
-                            cur = load_rec(q_in, idx);
-                            state = ST_MAIN;
-                        }
-                    } else if (exhausted && avail == 0) {
-                        state = ST_EMPTY;
-                    }
+                const uint32_t r = __popcll(mask & ((1ull << lane) - 1ull));
+                // staged children that can no longer go to the next depth's queue come first (newest first)
+                const uint32_t from_stage = queue_full ? (asking < stage_n ? asking : stage_n) : 0u;
+                if (want && r < from_stage) {
+                    cur = load_rec(staging, stage_n - 1 - r);
+                    state = ST_MAIN;
+                    ++n_spilled;
                 }
-                chunk_next += asking < avail ? asking : avail;
+                stage_n -= from_stage;
+                if (asking > from_stage) {
+                    if (chunk_next == chunk_end && !exhausted) {
+                        if ((unsigned long long)my_chunk * RT_REFILL_CHUNK >= n_in) {
+                            exhausted = true;
+                        } else {
+                            chunk_next = my_chunk * RT_REFILL_CHUNK;
+                            chunk_end = (n_in - chunk_next < RT_REFILL_CHUNK) ? n_in : chunk_next + RT_REFILL_CHUNK;
+                            my_chunk += n_waves;
+                        }
+                    }
+                    const uint32_t avail = chunk_end - chunk_next;
+                    const uint32_t asking2 = asking - from_stage;
+                    if (want && r >= from_stage) {
+                        const uint32_t r2 = r - from_stage;
+                        if (r2 < avail) {
+                            uint32_t idx = chunk_next + r2;
+                            if (level == 0) {
+                                uint32_t col, row;
+                                if (pixel_coords(F, idx, col, row)) {
+                                    cur.ray = primary_ray(F, col, row);
+                                    cur.throughput = 1.0f;
+                                    cur.meta = idx;
+                                    state = ST_MAIN;
+                                }                               // padding pixel: stay idle, ask again
+                            } else {
+                                cur = load_rec(q_in, idx);
+                                state = ST_MAIN;
+                            }
+                        } else if (exhausted && avail == 0) {
+                            state = ST_EMPTY;
+                        }
+                    }
+                    chunk_next += asking2 < avail ? asking2 : avail;
+                }
             }
         }
-        if (__all(state == ST_EMPTY)) break;
+        if (__all(state == ST_EMPTY)) {
+            // nothing left to trace: hand the staged children over; whatever does not fit stays here
+            if (stage_n > 0 && !queue_full) flush_staging(C, level, F.queue_capacity, q_out, staging, stage_n, queue_full, lane);
+            if (stage_n == 0) break;
+            state = ST_IDLE;
+            continue;
+        }
         RT_STAT(dbg_iters += (lane == 0) ? 1u : 0u);
 
         // ---- trace one ray per busy lane -------------------------------------------------------
@@ -792,44 +856,39 @@ rt_trace_level(const DScene S, const DFrame F, const uint32_t level) {
             }
         }
 
-        // ---- append the children to the next depth's queue: one atomic per wave -------------------
+        // ---- stage the children; move them to the next depth's queue when the buffer fills up ------
         {
             unsigned long long mask_r = __ballot(emit_r), mask_t = __ballot(emit_t);
             uint32_t total = __popcll(mask_r) + __popcll(mask_t);
             if (total) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&C->queue_count[level & 1], total);
-                base = __shfl(base, 0);
                 unsigned long long lt = (1ull << lane) - 1ull;
-                uint32_t at_r = base + __popcll(mask_r & lt);
-                uint32_t at_t = base + __popcll(mask_r) + __popcll(mask_t & lt);
+                uint32_t at_r = stage_n + __popcll(mask_r & lt);
+                uint32_t at_t = stage_n + __popcll(mask_r) + __popcll(mask_t & lt);
                 // children that do not fit are kept by this lane (transmitted first, so that the
                 // reflected one is traced first, as in the reference's evaluation order)
                 if (emit_t) {
-                    if (at_t < F.queue_capacity) store_rec(q_out, at_t, rec_t);
+                    if (at_t < RT_STAGING_RECORDS) store_rec(staging, at_t, rec_t);
                     else { store_rec(spill, spill_n, rec_t); ++spill_n; ++n_spilled; }
                 }
                 if (emit_r) {
-                    if (at_r < F.queue_capacity) store_rec(q_out, at_r, rec_r);
+                    if (at_r < RT_STAGING_RECORDS) store_rec(staging, at_r, rec_r);
                     else { store_rec(spill, spill_n, rec_r); ++spill_n; ++n_spilled; }
                 }
+                stage_n = (stage_n + total < RT_STAGING_RECORDS) ? stage_n + total : RT_STAGING_RECORDS;
+                if (!queue_full && stage_n > RT_STAGING_RECORDS - 2 * RT_WAVE)
+                    flush_staging(C, level, F.queue_capacity, q_out, staging, stage_n, queue_full, lane);
             }
         }
     }
 
-    // ---- ray statistics: one atomic per wave and counter ----------------------------------------
-    uint32_t vals[5] = {n_primary + n_shadow + n_reflected + n_transmitted, n_primary, n_shadow, n_reflected, n_transmitted};
-    for (int k = 0; k < 5; ++k) {
-        uint32_t v = vals[k];
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-#ifndef RT_ABLATE_STATS
-        if (lane == 0 && v) atomicAdd(&C->rays[k], (unsigned long long)v);
-#endif
-    }
+    // ---- ray statistics: every wave owns a row of F.wave_stats (no atomics) ------------------------
     {
-        uint32_t v = n_spilled;
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-        if (lane == 0 && v) atomicAdd(&C->spilled, v);
+        uint32_t vals[6] = {n_primary + n_shadow + n_reflected + n_transmitted, n_primary, n_shadow, n_reflected, n_transmitted, n_spilled};
+        for (int k = 0; k < 6; ++k) {
+            uint32_t v = vals[k];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+            if (lane == 0 && v) F.wave_stats[(size_t)gwave * 8 + k] += v;
+        }
     }
 #ifdef RT_STATS
     {
@@ -843,9 +902,8 @@ rt_trace_level(const DScene S, const DFrame F, const uint32_t level) {
 #endif
 }
 
-// Clears the cursor between passes and resets the queue that the next pass will fill.
+// Resets the count of the queue that the next pass will fill.
 __global__ void rt_next_level(DCounters* C, uint32_t next_level) {
-    C->cursor = 0;
     C->queue_count[next_level & 1] = 0;
 }
 
