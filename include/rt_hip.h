@@ -253,9 +253,11 @@ int rt_last_trace_ms(RtScene* scene, float* out_ms);
 
 void rt_scene_destroy(RtScene* scene);
 
-/* Test aids.  The first caps the per-depth ray queue at `capacity` rays (0 = the default, four rays
- * per pixel): children that do not fit are traced by the lane that produced them, with the same
- * result.  The second reports how many children took that route in the last frame. */
+/* Test aids.  The first sets how many rays a list of one recursion depth can hold (0 = the default,
+ * eight per pixel).  When a list overflows, the kernels raise a flag: rt_render then enlarges the lists
+ * and renders the frame again (the second call reports how often it had to for its last frame);
+ * after rt_render_device the overflow is reported by rt_last_ray_counts, and the next frame gets
+ * longer lists. */
 int rt_debug_set_queue_capacity(RtScene* scene, uint32_t capacity);
 int rt_debug_last_spilled(RtScene* scene, uint32_t* out_count);
 

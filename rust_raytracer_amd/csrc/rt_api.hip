@@ -14,13 +14,14 @@
 #include "rt_device.h"
 
 extern "C" {
-hipError_t rt_launch_trace_level(const DScene* S, const DFrame* F, uint32_t level, uint32_t blocks, hipStream_t stream);
-hipError_t rt_launch_next_level(DCounters* C, uint32_t next_level, hipStream_t stream);
+hipError_t rt_launch_generate(const DFrame* F, uint32_t blocks, hipStream_t stream);
+hipError_t rt_launch_level(const DScene* S, const DFrame* F, uint32_t level, uint32_t blocks, uint32_t traverse_blocks,
+                           hipStream_t stream);
 hipError_t rt_launch_resolve(const DFrame* F, uint8_t* out, uint32_t bytes_per_pixel, uint32_t tiled, hipStream_t stream);
 hipError_t rt_launch_resolve_aux(const DFrame* F, uint32_t* prim, uint32_t* inst, uint8_t* flags, hipStream_t stream);
 hipError_t rt_launch_assemble(const uint8_t* gathered, uint8_t* frame, uint32_t width, uint32_t height, uint32_t tiles_x,
                               uint32_t shard_count, uint32_t tiles_per_shard, uint32_t bytes_per_pixel, hipStream_t stream);
-int rt_query_trace_blocks_per_cu(uint32_t stack_entries);
+int rt_query_traverse_blocks_per_cu(uint32_t n_seg, uint32_t stack_entries);
 }
 
 static thread_local char g_error[512] = "";
@@ -46,7 +47,12 @@ struct RtScene {
     bool timed = false;
     hipStream_t last_stream = nullptr;
     int n_cus = 0;
-    int blocks_per_cu = 1;
+    uint32_t list_blocks = 0;           // grid of the list-producing kernels
+    uint32_t traverse_blocks = 0;       // grid of the BVH walk
+    unsigned int* h_overflow = nullptr; // host-mapped flag the kernels set when a list does not fit
+    unsigned int* d_overflow = nullptr;
+    uint32_t capacity_shift = 0;        // lists are (default capacity << capacity_shift) rays long
+    uint32_t regrown = 0;               // times rt_render had to enlarge the lists for its last frame
     std::vector<void*> scene_allocs;
     DScene d{};
     bool camera_set = false;
@@ -62,6 +68,7 @@ struct RtScene {
     uint8_t* d_aux_flags_out = nullptr;
     size_t aux_out_pixels = 0;
     uint32_t debug_queue_capacity = 0;
+    size_t stats_words = 0;
 };
 
 template <class T>
@@ -302,10 +309,16 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device_id, RtScene**
         (rc = upload(s, triangles, &s->d.triangles)) || (rc = upload(s, instances, &s->d.instances)) ||
         (rc = upload(s, nodes, &s->d.nodes)) || (rc = upload(s, hot, &s->d.tri_hot)) || (rc = upload(s, cold, &s->d.tri_cold)))
         return bail(rc);
-    int bpc = rt_query_trace_blocks_per_cu(stack_entries);
-    if (bpc < 1) return bail(fail(RT_ERR_DEVICE, "the trace kernel does not fit a compute unit"));
+    s->list_blocks = (uint32_t)s->n_cus * 4;
+    if (const char* env = getenv("RT_LIST_BLOCKS_PER_CU")) { int v = atoi(env); if (v >= 1 && v <= 8) s->list_blocks = (uint32_t)(s->n_cus * v); }
+    int bpc = rt_query_traverse_blocks_per_cu(s->list_blocks + 1, stack_entries);
+    if (bpc < 1) return bail(fail(RT_ERR_DEVICE, "the traversal kernel does not fit a compute unit"));
     if (const char* env = getenv("RT_BLOCKS_PER_CU")) { int v = atoi(env); if (v >= 1 && v <= bpc) bpc = v; }
-    s->blocks_per_cu = bpc;
+    s->traverse_blocks = (uint32_t)(s->n_cus * bpc);
+    if (hipHostMalloc((void**)&s->h_overflow, sizeof(unsigned int), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&s->d_overflow, s->h_overflow, 0) != hipSuccess)
+        return bail(fail(RT_ERR_DEVICE, "cannot allocate the host-visible overflow flag"));
+    *s->h_overflow = 0;
     *out_scene = s;
     return RT_OK;
 }
@@ -321,6 +334,7 @@ extern "C" void rt_scene_destroy(RtScene* s) {
     if (s->d_aux_prim_out) (void)hipFree(s->d_aux_prim_out);
     if (s->d_aux_inst_out) (void)hipFree(s->d_aux_inst_out);
     if (s->d_aux_flags_out) (void)hipFree(s->d_aux_flags_out);
+    if (s->h_overflow) (void)hipHostFree(s->h_overflow);
     if (s->ev_start) (void)hipEventDestroy(s->ev_start);
     if (s->ev_stop) (void)hipEventDestroy(s->ev_stop);
     if (s->ev_trace_start) (void)hipEventDestroy(s->ev_trace_start);
@@ -368,13 +382,20 @@ static int frame_alloc(RtScene* s, size_t count, T** out) {
     return RT_OK;
 }
 
+static uint32_t ceil_div(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
 static int ensure_frame(RtScene* s, const Geometry& g, uint32_t max_depth, bool aux) {
-    uint32_t blocks = (uint32_t)(s->n_cus * s->blocks_per_cu);
-    uint32_t capacity = s->debug_queue_capacity ? s->debug_queue_capacity : (g.n_pixels > (1u << 28) / 4 ? (1u << 28) : 4 * g.n_pixels);
-    if (const char* env = getenv("RT_QUEUE_CAPACITY")) { long v = atol(env); if (v > 0 && !s->debug_queue_capacity) capacity = (uint32_t)v; }
+    const uint32_t blocks = s->list_blocks;
+    // rays one depth may hold (its child rays and the shadow rays of the depth above): 8 per pixel to begin with
+    uint64_t capacity = s->debug_queue_capacity ? s->debug_queue_capacity : (uint64_t)8 * g.n_pixels;
+    if (const char* env = getenv("RT_QUEUE_CAPACITY")) { long v = atol(env); if (v > 0 && !s->debug_queue_capacity) capacity = (uint64_t)v; }
+    capacity <<= s->capacity_shift;
+    if (capacity < 4096) capacity = 4096;
+    if (capacity > (1ull << 30)) return fail(RT_ERR_OUT_OF_RANGE, "a frame needs more than 2^30 rays per depth");
     RtScene::FrameKey k;
-    k.w = g.n_pixels; k.h = 0; k.shard_count = g.shard_count; k.max_depth = max_depth; k.aux = aux; k.blocks = blocks; k.capacity = capacity;
-    bool same = k.w == s->key.w && k.max_depth == s->key.max_depth && k.blocks == s->key.blocks && k.capacity == s->key.capacity &&
+    k.w = g.n_pixels; k.h = s->d.n_lights; k.shard_count = g.shard_count; k.max_depth = max_depth; k.aux = aux; k.blocks = blocks;
+    k.capacity = (uint32_t)capacity;
+    bool same = k.w == s->key.w && k.h == s->key.h && k.blocks == s->key.blocks && k.capacity == s->key.capacity &&
                 (s->key.aux || !aux) && !s->frame_allocs.empty();
     if (!same) {
         HIP_TRY(hipDeviceSynchronize());
@@ -382,15 +403,31 @@ static int ensure_frame(RtScene* s, const Geometry& g, uint32_t max_depth, bool 
         s->frame_allocs.clear();
         DFrame& f = s->f;
         memset(&f, 0, sizeof(f));
+        f.n_seg = blocks + 1;
+        f.seg_rays = ceil_div(capacity, blocks);          f.ovf_rays = (uint32_t)(capacity / 4 + 1024);
+        f.seg_items = ceil_div(capacity / 2, blocks);     f.ovf_items = (uint32_t)(capacity / 8 + 1024);
+        f.seg_hits = ceil_div(capacity / 2, blocks);      f.ovf_hits = (uint32_t)(capacity / 8 + 1024);
+        const size_t ray_slots = (size_t)blocks * f.seg_rays + f.ovf_rays;
+        const size_t item_slots = (size_t)blocks * f.seg_items + f.ovf_items;
+        const size_t hit_slots = (size_t)blocks * f.seg_hits + f.ovf_hits;
+        const size_t flag_bytes = hit_slots * (s->d.n_lights ? s->d.n_lights : 1);
+        s->stats_words = (size_t)blocks * 4 * 8;
         int rc;
         if ((rc = frame_alloc(s, (size_t)3 * g.n_pixels, &f.acc)) || (rc = frame_alloc(s, g.n_pixels, &f.poison)) ||
-            (rc = frame_alloc(s, (size_t)2 * capacity, &f.queue[0])) || (rc = frame_alloc(s, (size_t)2 * capacity, &f.queue[1])) ||
-            (rc = frame_alloc(s, (size_t)blocks * 256 * max_depth * 2, &f.spill)) || (rc = frame_alloc(s, 1, &f.counters)) ||
-            (rc = frame_alloc(s, (size_t)blocks * 4 * 512 * 2, &f.staging)) || (rc = frame_alloc(s, (size_t)blocks * 4 * 8, &f.wave_stats)))
+            (rc = frame_alloc(s, 2 * ray_slots, &f.rays[0])) || (rc = frame_alloc(s, 2 * ray_slots, &f.rays[1])) ||
+            (rc = frame_alloc(s, f.n_seg, &f.ray_counts[0])) || (rc = frame_alloc(s, f.n_seg, &f.ray_counts[1])) ||
+            (rc = frame_alloc(s, ray_slots, &f.best)) ||
+            (rc = frame_alloc(s, item_slots, &f.items)) || (rc = frame_alloc(s, item_slots, &f.item_results)) ||
+            (rc = frame_alloc(s, f.n_seg, &f.item_counts)) ||
+            (rc = frame_alloc(s, 3 * hit_slots, &f.hits[0])) || (rc = frame_alloc(s, 3 * hit_slots, &f.hits[1])) ||
+            (rc = frame_alloc(s, f.n_seg, &f.hit_counts[0])) || (rc = frame_alloc(s, f.n_seg, &f.hit_counts[1])) ||
+            (rc = frame_alloc(s, flag_bytes, &f.shadow_flags[0])) || (rc = frame_alloc(s, flag_bytes, &f.shadow_flags[1])) ||
+            (rc = frame_alloc(s, s->stats_words, &f.wave_stats)))
             return rc;
         if (aux && ((rc = frame_alloc(s, g.n_pixels, &f.aux_flags)) || (rc = frame_alloc(s, g.n_pixels, &f.aux_prim)) ||
                     (rc = frame_alloc(s, g.n_pixels, &f.aux_inst))))
             return rc;
+        f.overflow = s->d_overflow;
         s->key = k;
     }
     DFrame& f = s->f;
@@ -400,11 +437,11 @@ static int ensure_frame(RtScene* s, const Geometry& g, uint32_t max_depth, bool 
     f.shard_index = g.shard_index; f.shard_count = g.shard_count;
     f.n_local_tiles = g.tiles_per_shard; f.n_pixels = g.n_pixels;
     f.max_depth = max_depth;
-    f.queue_capacity = capacity;
     return RT_OK;
 }
 
-// Enqueues one frame on `stream`: clear, one pass per recursion depth, resolve into d_out.
+// Enqueues one frame on `stream`: clear, primary rays, four launches per recursion depth (one more depth
+// than max_depth: the shadow rays of the deepest hits), resolve into d_out.
 static int enqueue_frame(RtScene* s, const RtRenderParams* p, bool sharded, bool aux, uint8_t* d_out) {
     HIP_TRY(hipSetDevice(s->device));
     Geometry g;
@@ -412,23 +449,25 @@ static int enqueue_frame(RtScene* s, const RtRenderParams* p, bool sharded, bool
     if (rc) return rc;
     uint32_t max_depth = p->max_depth ? p->max_depth : RT_DEFAULT_MAX_DEPTH;
     if (max_depth > RT_MAX_DEPTH_LIMIT) return fail(RT_ERR_INVALID_ARGUMENT, "max_depth %u exceeds the limit of %d", max_depth, RT_MAX_DEPTH_LIMIT);
+    if (s->d.n_lights > 255) return fail(RT_ERR_INVALID_ARGUMENT, "%u lights; at most 255 are supported", s->d.n_lights);
+    // a list of an earlier frame did not fit: that frame was invalid, this one gets longer lists
+    if (*s->h_overflow) { *s->h_overflow = 0; ++s->capacity_shift; }
     if ((rc = ensure_frame(s, g, max_depth, aux))) return rc;
     hipStream_t stream = p->stream ? (hipStream_t)p->stream : s->own_stream;
     s->last_stream = stream;
     DFrame f = s->f;
     if (!aux) f.aux_flags = f.aux_prim = f.aux_inst = nullptr;
-    uint32_t blocks = (uint32_t)(s->n_cus * s->blocks_per_cu);
     HIP_TRY(hipEventRecord(s->ev_start, stream));
     HIP_TRY(hipMemsetAsync(f.acc, 0, (size_t)3 * g.n_pixels * sizeof(long long), stream));
     HIP_TRY(hipMemsetAsync(f.poison, 0, (size_t)g.n_pixels * sizeof(unsigned int), stream));
-    HIP_TRY(hipMemsetAsync(f.counters, 0, sizeof(DCounters), stream));
-    HIP_TRY(hipMemsetAsync(f.wave_stats, 0, (size_t)blocks * 4 * 8 * sizeof(unsigned int), stream));
+    HIP_TRY(hipMemsetAsync(f.wave_stats, 0, s->stats_words * sizeof(unsigned int), stream));
+    HIP_TRY(hipMemsetAsync(f.ray_counts[0], 0, f.n_seg * sizeof(unsigned int), stream));
     if (aux) HIP_TRY(hipMemsetAsync(f.aux_flags, 0, (size_t)g.n_pixels * sizeof(unsigned int), stream));
     HIP_TRY(hipEventRecord(s->ev_trace_start, stream));
-    for (uint32_t level = 0; level < max_depth; ++level) {
-        if (level > 0) HIP_TRY(rt_launch_next_level(f.counters, level, stream));
-        HIP_TRY(rt_launch_trace_level(&s->d, &f, level, blocks, stream));
-    }
+    HIP_TRY(rt_launch_generate(&f, s->list_blocks, stream));
+    const uint32_t last = s->d.n_lights > 0 ? max_depth : max_depth - 1;
+    for (uint32_t level = 0; level <= last; ++level)
+        HIP_TRY(rt_launch_level(&s->d, &f, level, s->list_blocks, s->traverse_blocks, stream));
     HIP_TRY(hipEventRecord(s->ev_trace_stop, stream));
     HIP_TRY(rt_launch_resolve(&f, d_out, bytes_per_pixel(p->output_format), g.shard_count > 1 ? 1u : 0u, stream));
     HIP_TRY(hipEventRecord(s->ev_stop, stream));
@@ -464,28 +503,36 @@ extern "C" int rt_render(RtScene* s, const RtRenderParams* p, uint8_t* out_pixel
         s->d_pixels_bytes = bytes;
     }
     bool want_aux = aux && (aux->prim_id || aux->instance_id || aux->flags);
-    int rc = enqueue_frame(s, p, false, want_aux, s->d_pixels);
-    if (rc) return rc;
-    hipStream_t stream = s->last_stream;
-    if (want_aux) {
-        if (s->aux_out_pixels < n) {
-            if (s->d_aux_prim_out) (void)hipFree(s->d_aux_prim_out);
-            if (s->d_aux_inst_out) (void)hipFree(s->d_aux_inst_out);
-            if (s->d_aux_flags_out) (void)hipFree(s->d_aux_flags_out);
-            s->d_aux_prim_out = s->d_aux_inst_out = nullptr; s->d_aux_flags_out = nullptr; s->aux_out_pixels = 0;
-            HIP_TRY(hipMalloc((void**)&s->d_aux_prim_out, n * 4));
-            HIP_TRY(hipMalloc((void**)&s->d_aux_inst_out, n * 4));
-            HIP_TRY(hipMalloc((void**)&s->d_aux_flags_out, n));
-            s->aux_out_pixels = n;
+    s->regrown = 0;
+    for (;;) {
+        int rc = enqueue_frame(s, p, false, want_aux, s->d_pixels);
+        if (rc) return rc;
+        hipStream_t stream = s->last_stream;
+        if (want_aux) {
+            if (s->aux_out_pixels < n) {
+                if (s->d_aux_prim_out) (void)hipFree(s->d_aux_prim_out);
+                if (s->d_aux_inst_out) (void)hipFree(s->d_aux_inst_out);
+                if (s->d_aux_flags_out) (void)hipFree(s->d_aux_flags_out);
+                s->d_aux_prim_out = s->d_aux_inst_out = nullptr; s->d_aux_flags_out = nullptr; s->aux_out_pixels = 0;
+                HIP_TRY(hipMalloc((void**)&s->d_aux_prim_out, n * 4));
+                HIP_TRY(hipMalloc((void**)&s->d_aux_inst_out, n * 4));
+                HIP_TRY(hipMalloc((void**)&s->d_aux_flags_out, n));
+                s->aux_out_pixels = n;
+            }
+            DFrame f = s->f;
+            HIP_TRY(rt_launch_resolve_aux(&f, s->d_aux_prim_out, s->d_aux_inst_out, s->d_aux_flags_out, stream));
+            if (aux->prim_id) HIP_TRY(hipMemcpyAsync(aux->prim_id, s->d_aux_prim_out, n * 4, hipMemcpyDeviceToHost, stream));
+            if (aux->instance_id) HIP_TRY(hipMemcpyAsync(aux->instance_id, s->d_aux_inst_out, n * 4, hipMemcpyDeviceToHost, stream));
+            if (aux->flags) HIP_TRY(hipMemcpyAsync(aux->flags, s->d_aux_flags_out, n, hipMemcpyDeviceToHost, stream));
         }
-        DFrame f = s->f;
-        HIP_TRY(rt_launch_resolve_aux(&f, s->d_aux_prim_out, s->d_aux_inst_out, s->d_aux_flags_out, stream));
-        if (aux->prim_id) HIP_TRY(hipMemcpyAsync(aux->prim_id, s->d_aux_prim_out, n * 4, hipMemcpyDeviceToHost, stream));
-        if (aux->instance_id) HIP_TRY(hipMemcpyAsync(aux->instance_id, s->d_aux_inst_out, n * 4, hipMemcpyDeviceToHost, stream));
-        if (aux->flags) HIP_TRY(hipMemcpyAsync(aux->flags, s->d_aux_flags_out, n, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(out_pixels, s->d_pixels, bytes, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (!*s->h_overflow) break;
+        // a ray list did not fit: enlarge (enqueue_frame sees the flag) and render the frame again
+        ++s->regrown;
+        if (s->regrown > 16) return fail(RT_ERR_OUT_OF_RANGE, "the ray lists keep overflowing");
     }
-    HIP_TRY(hipMemcpyAsync(out_pixels, s->d_pixels, bytes, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
+    int rc = RT_OK;
     if (aux) {
         memset(aux->counters, 0, sizeof(aux->counters));
         rc = rt_last_ray_counts(s, aux->counters);
@@ -511,7 +558,7 @@ extern "C" int rt_assemble_shards(RtScene* s, const RtRenderParams* p, const voi
 }
 
 static int sum_wave_stats(RtScene* s, uint64_t sums[8]) {
-    size_t n = (size_t)s->key.blocks * 4 * 8;
+    size_t n = s->stats_words;
     std::vector<unsigned int> host(n);
     HIP_TRY(hipMemcpy(host.data(), s->f.wave_stats, n * sizeof(unsigned int), hipMemcpyDeviceToHost));
     for (int k = 0; k < 8; ++k) sums[k] = 0;
@@ -524,6 +571,8 @@ extern "C" int rt_last_ray_counts(RtScene* s, uint64_t counters[RT_N_COUNTERS]) 
     if (!s->timed) return fail(RT_ERR_INVALID_ARGUMENT, "nothing has been rendered on this handle yet");
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipStreamSynchronize(s->last_stream));
+    if (*s->h_overflow)
+        return fail(RT_ERR_OUT_OF_RANGE, "a ray list overflowed during the last frame: its output is incomplete; the next frame gets longer lists");
     uint64_t sums[8];
     int rc = sum_wave_stats(s, sums);
     if (rc) return rc;
@@ -563,23 +612,10 @@ extern "C" int rt_debug_last_spilled(RtScene* s, uint32_t* out) {
     if (!s->timed) return fail(RT_ERR_INVALID_ARGUMENT, "nothing has been rendered on this handle yet");
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipStreamSynchronize(s->last_stream));
-    uint64_t sums[8];
-    int rc = sum_wave_stats(s, sums);
-    if (rc) return rc;
-    *out = (uint32_t)sums[5];
+    *out = s->regrown;
     return RT_OK;
 }
 
-#ifdef RT_STATS
-extern "C" int rt_debug_stats(RtScene* s, unsigned long long* out /* [64][7] */) {
-    HIP_TRY(hipSetDevice(s->device));
-    HIP_TRY(hipStreamSynchronize(s->last_stream));
-    DCounters c;
-    HIP_TRY(hipMemcpy(&c, s->f.counters, sizeof(c), hipMemcpyDeviceToHost));
-    memcpy(out, c.dbg, sizeof(c.dbg));
-    return RT_OK;
-}
-#endif
 
 extern "C" const char* rt_last_error(void) { return g_error; }
 

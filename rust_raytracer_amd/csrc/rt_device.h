@@ -3,7 +3,7 @@
 // Everything the per-ray code reads is laid out for the way a wave64 reads it:
 //  * the few analytic primitives, lights and materials are small arrays read with wave-uniform
 //    indices (the compiler turns those into scalar loads);
-//  * BVH nodes are 32 B (two 16-B loads, two nodes per 64-B line);
+//  * an inner BVH node is 64 B and holds the boxes of both children (one line, one round trip);
 //  * mesh triangles are re-ordered so that the triangles of a leaf are consecutive, 48 B of "hot"
 //    data per triangle (first vertex and the two edge vectors the Moeller-Trumbore test starts
 //    from) and 48 B of "cold" data (normals) read only for the winning hit.
@@ -86,15 +86,13 @@ struct DScene {
 };
 
 // Per-frame device state.
-struct DCounters {
-    unsigned int queue_count[2];     // rays appended to each of the two queues (may exceed capacity)
-#ifdef RT_STATS
-    // diagnostic build only, per depth: inner nodes visited, leaves visited, triangles tested, instance
-    // set-ups, traversal loop trips (per wave), lane transitions, outer loop trips (per wave)
-    unsigned long long dbg[64][7];
-#endif
-};
-
+//
+// Work lists (rays, BVH work items, hit records) are cut into one segment per producer block plus
+// one shared overflow segment.  A block appends to its own segment through a counter in LDS - no
+// device-wide atomic is involved - and stores the final count at the end of the kernel; the
+// consumer kernel turns the counts into a prefix table (in LDS) and walks the concatenation of
+// all segments in interleaved 64-element chunks, so that work is spread evenly again whatever
+// block produced it.
 struct DFrame {
     float screen_to_world[16];       // column-major
     uint32_t width, height;
@@ -103,15 +101,24 @@ struct DFrame {
     uint32_t n_local_tiles;          // tiles this shard owns (rounded up so every shard has the same number)
     uint32_t n_pixels;               // n_local_tiles * RT_TILE_DIM^2
     uint32_t max_depth;
-    uint32_t queue_capacity;
+    uint32_t n_seg;                  // producer blocks + 1 (the last segment is the shared overflow segment)
+    uint32_t seg_rays, ovf_rays;     // capacity of a block's ray segment / of the overflow segment
+    uint32_t seg_items, ovf_items;
+    uint32_t seg_hits, ovf_hits;
     long long* acc;                  // [3][n_pixels] fixed-point colour sums, 2^-40 units
     unsigned int* poison;            // [n_pixels] non-finite contributions, see rt_kernels.hip
     unsigned int* aux_flags;         // [n_pixels] or null
     unsigned int* aux_prim;          // [n_pixels] or null
     unsigned int* aux_inst;          // [n_pixels] or null
-    float4* queue[2];                // ray records, 2 float4 each
-    float4* spill;                   // [threads][max_depth][2]
-    float4* staging;                 // [waves][512][2] children waiting to be moved to a queue
-    unsigned int* wave_stats;        // [waves][8]: rays, primary, shadow, reflected, transmitted, kept-by-parent
-    DCounters* counters;
+    float4* rays[2];                 // ray records of the current / next depth, 2 float4 each
+    unsigned int* ray_counts[2];     // [n_seg]
+    unsigned long long* best;        // [ray slots] closest candidate so far: t bits << 32 | order, see rt_kernels.hip
+    uint2* items;                    // BVH work items: (ray slot, instance | flags)
+    float4* item_results;            // per item: local t, u, v, bits triangle slot
+    unsigned int* item_counts;       // [n_seg]
+    float4* hits[2];                 // Phong-shaded hits waiting for their shadow rays, 3 float4 each
+    unsigned int* hit_counts[2];     // [n_seg]
+    unsigned char* shadow_flags[2];  // [hit slots][n_lights]
+    unsigned int* wave_stats;        // [waves][8]: rays, primary, shadow, reflected, transmitted
+    unsigned int* overflow;          // set to 1 when a list did not fit (the frame is then invalid)
 };

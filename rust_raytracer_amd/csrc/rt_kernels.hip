@@ -10,17 +10,18 @@
 //    ray carries the product of the weights on its path ("throughput") and every ray adds
 //    throughput * local colour to its pixel.  Sums are kept in 2^-40 fixed point with integer
 //    atomics, so the result does not depend on the order in which rays finish.
-//  * Rays of recursion depth d live in a queue in HBM (32 B per ray); one launch per depth consumes
-//    queue d and appends the reflected / transmitted children to queue d+1.  A launch is a
-//    persistent grid: every lane pulls rays from the queue until it is empty, so lanes whose ray is
-//    finished are refilled and terminated rays are compacted away (wave-aggregated atomics on the
-//    queue cursor, one per wave and refill).
-//  * A lane is a small state machine: MAIN (closest hit of its ray) then one SHADOW state per light
-//    (the shadow ray of raytracer.rs:78) - every trip round the loop traces exactly one ray through
-//    the same inlined scene traversal, whatever state the lane is in.
-//  * The BVH traversal stack of intersect.rs:240-256 is a per-lane column of LDS
-//    (stack[entry][lane], conflict-free); an inner node is 64 B and carries the boxes of both
-//    children; the triangles of a leaf are consecutive.
+//  * All rays of one recursion depth - and the shadow rays of the hits one depth up - form a list
+//    in HBM (32 B per ray).  Each depth is four dense launches over such lists:
+//      A  rt_setup     analytic primitives + root-box test of every mesh instance per ray; emits
+//                      one BVH work item per (ray, instance) that needs a walk
+//      B  rt_traverse  BVH walk, one work item per lane, lanes refilled as they finish - every
+//                      lane that is busy is busy with the same code
+//      C  rt_shade     closest hit -> hit point, material, child rays and shadow rays
+//      D  rt_phong     Phong sums of the previous depth's hits once their shadow rays are back
+//    Splitting by kind of work is what keeps the 64 lanes of a wave busy: in a one-kernel version
+//    fewer than 5 % of the lanes had a BVH node to visit in a given round.
+//  * Lists are appended to without device-wide atomics (about 10 ns each when contended, all
+//    waves serialised): every block owns a segment of each output list, see rt_device.h.
 //
 // Every arithmetic expression that feeds a hit decision keeps the operation order of the reference
 // (see the citations at each function); the file must be compiled with -ffp-contract=off and
@@ -31,8 +32,6 @@
 
 #define RT_BLOCK_THREADS 256
 #define RT_WAVE 64
-#define RT_REFILL_CHUNK 64u
-#define RT_STAGING_RECORDS 512u
 
 namespace {
 
@@ -187,232 +186,9 @@ __device__ __forceinline__ bool slab(float lx, float ly, float lz, float hx, flo
 
 #define RT_INF __uint_as_float(0x7F800000u)
 
-// Diagnostic build (-DRT_STATS): per-launch totals of traversal events, see DCounters::dbg.
-#ifdef RT_STATS
-struct DbgStats { uint32_t inner, leaf, tris, setups, rounds, transitions; };
-#define RT_STAT(x) (x)
-#else
-#define RT_STAT(x) ((void)0)
-#endif
+
 // Pruning slack, see trace_scene: relative part of every "is this box beyond the best hit" comparison.
 #define RT_PRUNE_REL 1.015625f            // 1 + 2^-6
-
-// Closest hit of `r` against the whole scene with the outcome of scene.rs:120-140.
-//
-// `stack` points at this lane's column of the wave's LDS stack: entry e of the reference column is
-// stack[e * RT_WAVE], its box-entry distance is stack[(entries + e) * RT_WAVE].
-//
-// Mesh traversal visits fewer nodes than intersect.rs:228-269 does, without changing the result:
-//  * A node's box is tested when its parent is visited (the parent holds both child boxes), with
-//    the reference's arithmetic, so the set of boxes that "pass" is the reference's.
-//  * Distance pruning: a box whose entry distance lies beyond the best candidate so far (or beyond
-//    `limit_world`: the best hit of earlier primitives, or the light of a shadow ray) by more than
-//    the slack cannot hold a candidate that compares lower.  The slack (RT_PRUNE_REL and the
-//    instance's prune_abs) dominates the rounding error of Moeller-Trumbore's t for the triangle
-//    sizes of a `prunable` mesh; other meshes are walked exactly as the reference walks them.
-//  * Near child first.  The reference resolves equal t by visiting order (utils/mod.rs:17, strict
-//    `<`); triangle slots are numbered in that visiting order, so "lower slot wins a tie" gives the
-//    same winner in any visiting order.
-//  * Rays with a non-finite component take the reference's order and no pruning; a NaN candidate
-//    ends the walk because nothing can replace it.
-// any_hit (shadow rays, raytracer.rs:171-187): the caller only needs `have && t < limit_world`
-// (or `have` for a directional light), so the walk stops at the first candidate that settles it.
-__device__ __forceinline__ void trace_scene(const DScene& S, const Ray& r, uint32_t* stack, Closest& best,
-                                            const float limit_world, const bool any_hit, const bool directional
-#ifdef RT_STATS
-                                            , DbgStats& dbg
-#endif
-                                            ) {
-    best.have = false;
-    best.t = 0.0f;
-    best.prim = RT_PRIM_NONE;
-    best.inst = RT_INSTANCE_NONE;
-    best.tl = best.u = best.v = 0.0f;
-    best.slot = 0;
-    const bool ray_finite = finite3(r.o) && finite3(r.d);
-    // a shadow ray may stop as soon as one candidate proves "shadow"; with NaNs about only the
-    // directional case is decided by the mere existence of a candidate
-    const bool early = any_hit && (directional || ray_finite);
-
-    // planes.as_slice().intersect(ray): intersect.rs:20-36 then the merge of scene.rs:129
-    {
-        bool g_have = false; float g_t = 0.0f; uint32_t g_i = 0;
-        for (uint32_t i = 0; i < S.n_planes; ++i) {
-            float t;
-            if (plane_t(S.planes[i], r, t) && closer(g_have, g_t, t)) { g_have = true; g_t = t; g_i = i; }
-        }
-        if (g_have && closer(best.have, best.t, g_t)) { best.have = true; best.t = g_t; best.prim = ((uint32_t)RT_PRIM_PLANE << 30) | g_i; }
-    }
-    if (early && best.have && (directional || best.t < limit_world)) return;
-    {
-        bool g_have = false; float g_t = 0.0f; uint32_t g_i = 0;
-        for (uint32_t i = 0; i < S.n_spheres; ++i) {
-            float t;
-            if (sphere_t(S.spheres[i], r, t) && closer(g_have, g_t, t)) { g_have = true; g_t = t; g_i = i; }
-        }
-        if (g_have && closer(best.have, best.t, g_t)) { best.have = true; best.t = g_t; best.prim = ((uint32_t)RT_PRIM_SPHERE << 30) | g_i; }
-    }
-    if (early && best.have && (directional || best.t < limit_world)) return;
-    {
-        bool g_have = false; float g_t = 0.0f; uint32_t g_i = 0;
-        for (uint32_t i = 0; i < S.n_triangles; ++i) {
-            const DTriangle& tr = S.triangles[i];
-            float t, u, v;
-            if (triangle_tuv(ld3(tr.p0), ld3(tr.e1), ld3(tr.e2), r, t, u, v) && closer(g_have, g_t, t)) {
-                g_have = true; g_t = t; g_i = i;
-            }
-        }
-        if (g_have && closer(best.have, best.t, g_t)) { best.have = true; best.t = g_t; best.prim = ((uint32_t)RT_PRIM_TRIANGLE << 30) | g_i; }
-    }
-    if (early && best.have && (directional || best.t < limit_world)) return;
-
-    uint32_t* stack_t = stack + S.stack_entries * RT_WAVE;
-    const float o_l1 = fabsf(r.o.x) + fabsf(r.o.y) + fabsf(r.o.z);
-
-    // Mesh instances in Vec order: intersect.rs:290-326 around 228-269.  Every lane walks its own
-    // sequence instance 0, 1, ... and steps through one BVH node per trip of the loop below, so a lane
-    // that is done with an instance does not wait for the lanes still inside it.  Entering and leaving
-    // an instance (transforms, root test, world-space t) is the expensive, divergent part: lanes that
-    // need it wait until a quarter of the wave does, or until no lane has a node left to visit.
-    uint32_t next_inst = 0, cur_inst = 0;
-    bool in_mesh = false, done = false;
-    uint32_t sp = 0;
-    Ray lr;
-    lr.o = lr.d = mk(0, 0, 0);
-    V3 inv = mk(0, 0, 0);
-    bool fast = false;
-    float limit = RT_INF, prune_abs = 0.0f, slack_w = 0.0f;
-    bool m_have = false; float m_t = 0.0f, m_u = 0.0f, m_v = 0.0f; uint32_t m_slot = 0;
-
-    for (;;) {
-        const bool waiting = !done && sp == 0;
-        const unsigned long long wait_mask = __ballot(waiting);
-        const unsigned long long run_mask = __ballot(!done && sp > 0);
-        if (!wait_mask && !run_mask) break;
-        RT_STAT(dbg.rounds += (__ffsll((long long)(wait_mask | run_mask)) - 1 == (int)(threadIdx.x & 63)) ? 1u : 0u);
-        if (waiting && (run_mask == 0 || __popcll(wait_mask) >= 16)) {
-            RT_STAT(dbg.transitions += 1);
-            if (in_mesh) {
-                in_mesh = false;
-                if (m_have) {
-                    // world-space t of this instance's closest hit: intersect.rs:312-319
-                    const DInstance& inst = S.instances[cur_inst];
-                    float4 h2 = S.tri_hot[3 * m_slot + 2];
-                    V3 fn = mk(h2.y, h2.z, h2.w);
-                    V3 p = lr.o + lr.d * m_t;
-                    bool front = dot3(fn, lr.d) < 0.0f;
-                    V3 sn = front ? fn : -fn;
-                    V3 pos_local = p + sn * 1e-4f;
-                    V3 pos_world = transform34(inst.model, pos_local);
-                    float tw = distance3(r.o, pos_world);
-                    if (closer(best.have, best.t, tw)) {
-                        best.have = true; best.t = tw; best.inst = cur_inst; best.slot = m_slot;
-                        best.tl = m_t; best.u = m_u; best.v = m_v;
-                        best.prim = ((uint32_t)RT_PRIM_MESH_TRIANGLE << 30) | __float_as_uint(S.tri_cold[3 * m_slot].w);
-                    }
-                    if (early && best.have && (directional || best.t < limit_world)) done = true;
-                }
-            }
-            if (best.have && best.t != best.t) done = true;     // a NaN closest hit is final (utils/mod.rs:17)
-            while (!done && !in_mesh && next_inst < S.n_instances) {
-                const uint32_t ii = next_inst++;
-                RT_STAT(dbg.setups += 1);
-                const DInstance& inst = S.instances[ii];
-                if (inst.root_ref == RT_REF_NONE) continue;     // empty node range, intersect.rs:235-237
-                lr.o = transform34(inst.model_inverse, r.o);
-                V3 dv = transform34(inst.rotation_scale_inverse, r.d);
-                float dn = sqrtf(dot3(dv, dv));
-                lr.d = mk(dv.x / dn, dv.y / dn, dv.z / dn);     // glm::normalize
-                inv = mk(1.0f / lr.d.x, 1.0f / lr.d.y, 1.0f / lr.d.z);
-                fast = inst.prunable && ray_finite && finite3(lr.o) && finite3(lr.d);
-                slack_w = 2.0f * inst.world_guard;
-                // mesh-local bound on useful t: a hit at world distance w lies at local t = w * dn (up to world_guard)
-                limit = RT_INF;
-                if (fast) {
-                    float lw = limit_world;
-                    if (best.have && best.t < lw) lw = best.t;
-                    if (lw < RT_INF) limit = (lw + slack_w + 1.52587890625e-05f * (o_l1 + lw)) * dn * 1.0009765625f;
-                }
-                prune_abs = inst.prune_abs;
-                float root_tmin;
-                if (!slab(inst.root_lo[0], inst.root_lo[1], inst.root_lo[2], inst.root_hi[0], inst.root_hi[1], inst.root_hi[2], lr.o, inv, root_tmin))
-                    continue;
-                if (fast && root_tmin > limit * RT_PRUNE_REL + prune_abs) continue;
-                m_have = false; m_t = 0.0f; m_u = 0.0f; m_v = 0.0f; m_slot = 0;
-                stack[0] = inst.root_ref;
-                stack_t[0] = __float_as_uint(root_tmin);
-                sp = 1;
-                cur_inst = ii;
-                in_mesh = true;
-            }
-            if (!in_mesh) done = true;
-        }
-        if (!done && sp > 0) {
-            --sp;
-            const uint32_t ref = stack[sp * RT_WAVE];
-            const float entry = __uint_as_float(stack_t[sp * RT_WAVE]);
-            float cut = RT_INF;                                 // boxes entered beyond this cannot matter
-            if (fast) {
-                float lim = (m_have && m_t < limit) ? m_t : limit;
-                cut = lim * RT_PRUNE_REL + prune_abs;
-            }
-            if (entry > cut) continue;
-            if (ref & RT_REF_LEAF_BIT) {
-                const uint32_t first = ref & RT_REF_SLOT_MASK;
-                const uint32_t cnt = (ref >> RT_REF_COUNT_SHIFT) & 7u;
-                bool improved = false;
-                RT_STAT(dbg.leaf += 1);
-                RT_STAT(dbg.tris += cnt);
-                for (uint32_t k = 0; k < cnt; ++k) {
-                    const uint32_t slot = first + k;
-                    float4 h0 = S.tri_hot[3 * slot];
-                    float4 h1 = S.tri_hot[3 * slot + 1];
-                    float4 h2 = S.tri_hot[3 * slot + 2];
-                    float t, u, v;
-                    if (triangle_tuv(mk(h0.x, h0.y, h0.z), mk(h0.w, h1.x, h1.y), mk(h1.z, h1.w, h2.x), lr, t, u, v) &&
-                        (!m_have || t < m_t || (t == m_t && slot < m_slot))) {
-                        m_have = true; m_t = t; m_u = u; m_v = v; m_slot = slot;
-                        improved = true;
-                    }
-                }
-                if (m_have && m_t != m_t) sp = 0;               // NaN candidate: final
-                if (early && improved) {
-                    // would this candidate already prove "shadow"?  The instance's final hit has a local t
-                    // that is not larger, hence a world t that is at most 2 * world_guard larger.
-                    const DInstance& inst = S.instances[cur_inst];
-                    float4 h2 = S.tri_hot[3 * m_slot + 2];
-                    V3 fn = mk(h2.y, h2.z, h2.w);
-                    V3 p = lr.o + lr.d * m_t;
-                    V3 sn = (dot3(fn, lr.d) < 0.0f) ? fn : -fn;
-                    float tw = distance3(r.o, transform34(inst.model, p + sn * 1e-4f));
-                    if (directional || tw < limit_world - (slack_w + 6.103515625e-05f * (o_l1 + limit_world))) {
-                        best.have = true; best.t = tw;
-                        done = true;
-                        sp = 0;
-                    }
-                }
-            } else {
-                RT_STAT(dbg.inner += 1);
-                const float4 n0 = S.nodes[4 * ref], n1 = S.nodes[4 * ref + 1], n2 = S.nodes[4 * ref + 2], n3 = S.nodes[4 * ref + 3];
-                float tl, tr;
-                bool hl = slab(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, lr.o, inv, tl);
-                bool hr = slab(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, lr.o, inv, tr);
-                hl = hl && !(tl > cut);
-                hr = hr && !(tr > cut);
-                uint32_t rl = __float_as_uint(n3.x), rr = __float_as_uint(n3.y);
-                // reference order: push left, push right, so that right is popped first (intersect.rs:253-256);
-                // on the fast path the nearer child is popped first instead
-                if (fast && tl < tr) {
-                    uint32_t tu = rl; rl = rr; rr = tu;
-                    float tf = tl; tl = tr; tr = tf;
-                    bool tb = hl; hl = hr; hr = tb;
-                }
-                if (hl) { stack[sp * RT_WAVE] = rl; stack_t[sp * RT_WAVE] = __float_as_uint(tl); ++sp; }
-                if (hr) { stack[sp * RT_WAVE] = rr; stack_t[sp * RT_WAVE] = __float_as_uint(tr); ++sp; }
-            }
-        }
-    }
-}
 
 // Full hitpoint of the winner.
 __device__ __forceinline__ Hitpoint finalize_hit(const DScene& S, const Ray& r, const Closest& c) {
@@ -482,9 +258,6 @@ __device__ __forceinline__ float fresnel_reflection(V3 refl_d, V3 trans_d, V3 N,
 
 __device__ __forceinline__ void add_channel(const DFrame& F, uint32_t pixel, int c, float v) {
     if (v == 0.0f) return;
-#ifdef RT_ABLATE_ATOMICS
-    if (v != 12345.678f) return;      // timing experiment only: results are wrong
-#endif
     if (fabsf(v) < RT_FIXED_LIMIT) {
         long long q = __double2ll_rn((double)v * RT_FIXED_ONE);
         atomicAdd(reinterpret_cast<unsigned long long*>(F.acc + (size_t)c * F.n_pixels + pixel), (unsigned long long)q);
@@ -552,214 +325,564 @@ __device__ __forceinline__ Ray primary_ray(const DFrame& F, uint32_t col, uint32
     return r;
 }
 
-enum { ST_IDLE = 0, ST_MAIN = 1, ST_SHADOW = 2, ST_EMPTY = 3 };
 
-// Moves a wave's staged ray records to the output queue: one atomic reserves the space, the lanes copy.
-// Records beyond the queue's capacity stay (moved to the front of the staging buffer) and `queue_full`
-// is set.  Must be called by all 64 lanes.
-__device__ __forceinline__ void flush_staging(DCounters* C, uint32_t level, uint32_t capacity, float4* q_out, float4* staging,
-                                              uint32_t& stage_n, bool& queue_full, uint32_t lane) {
+// ---- work lists ------------------------------------------------------------------------------------
+
+#define RT_KEY_NONE 0xFFFFFFFFFFFFFFFFull
+#define RT_KEY_MESH 0x80000000u          // low word: bit 31 set = BVH work item index, clear = analytic primitive
+#define RT_ITEM_DONE 0x80000000u         // item.y flag: result already final (ray traced on the exact path)
+#define RT_RAY_SHADOW 0x80000000u        // ray meta: shadow ray; low 8 bits = light index, record.w = bits(hit slot)
+#define RT_HIT_DEPTH0 0x80000000u        // hit record pixel word: the hit belongs to a primary ray
+
+// Candidate order as one integer: smaller t first; at equal t the candidate the reference meets first
+// (planes, spheres, triangles, then mesh instances in Vec order: scene.rs:129-136 with the strict `<`
+// of utils/mod.rs:17).  Only used for rays whose components are all finite: their t are finite and
+// >= 0, and the bit pattern of a non-negative float grows with its value.
+__device__ __forceinline__ unsigned long long make_key(float t, uint32_t order) {
+    uint32_t tb = (t == 0.0f) ? 0u : __float_as_uint(t);          // -0.0 compares equal to +0.0
+    return ((unsigned long long)tb << 32) | order;
+}
+__device__ __forceinline__ uint32_t analytic_order(uint32_t kind, uint32_t index) { return (kind << 29) | index; }
+
+// Exclusive prefix of the segment counts into `pre[0..n_seg]` (LDS); `scratch` is blockDim.x words of
+// LDS.  Block-wide: every thread of the block must call it.  Returns the total.
+__device__ uint32_t build_prefix(const unsigned int* counts, uint32_t n_seg, uint32_t seg_cap, uint32_t ovf_cap,
+                                 uint32_t* pre, uint32_t* scratch) {
+    const uint32_t t = threadIdx.x, nt = blockDim.x;
+    const uint32_t per = (n_seg + nt - 1) / nt;
+    const uint32_t b0 = t * per;
+    uint32_t sum = 0;
+    for (uint32_t i = b0; i < b0 + per && i < n_seg; ++i) {
+        uint32_t c = counts[i], cap = (i + 1 == n_seg) ? ovf_cap : seg_cap;
+        sum += c < cap ? c : cap;
+    }
+    scratch[t] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < nt; off <<= 1) {
+        uint32_t v = t >= off ? scratch[t - off] : 0u;
+        __syncthreads();
+        scratch[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = scratch[t] - sum;
+    for (uint32_t i = b0; i < b0 + per && i < n_seg; ++i) {
+        uint32_t c = counts[i], cap = (i + 1 == n_seg) ? ovf_cap : seg_cap;
+        pre[i] = run;
+        run += c < cap ? c : cap;
+    }
+    if (t == nt - 1) pre[n_seg] = scratch[nt - 1];
+    __syncthreads();
+    return pre[n_seg];
+}
+
+// Element v of the concatenated segments -> its slot in the backing array.
+__device__ __forceinline__ uint32_t locate(const uint32_t* pre, uint32_t n_seg, uint32_t seg_cap, uint32_t v) {
+    uint32_t lo = 0, hi = n_seg;
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (pre[mid] <= v) lo = mid; else hi = mid;
+    }
+    return lo * seg_cap + (v - pre[lo]);          // the overflow segment starts at (n_seg - 1) * seg_cap
+}
+
+// A slot of this block's output segment for every lane that wants one (RT_REF_NONE otherwise, or when
+// even the overflow segment is full).  Must be called by all lanes of the wave.
+__device__ __forceinline__ uint32_t append_slot(bool want, uint32_t* lds_counter, uint32_t seg_cap, uint32_t n_seg,
+                                                unsigned int* counts, uint32_t ovf_cap, unsigned int* overflow_flag,
+                                                uint32_t lane) {
+    unsigned long long mask = __ballot(want);
+    if (!mask) return RT_REF_NONE;
+    uint32_t leader = __ffsll((long long)mask) - 1;
     uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(&C->queue_count[level & 1], stage_n);
-    base = __shfl(base, 0);
-    uint32_t fit = 0;
-    if (base < capacity) fit = (capacity - base < stage_n) ? capacity - base : stage_n;
-    for (uint32_t i = lane; i < fit; i += RT_WAVE) {
-        float4 a = staging[2 * (size_t)i], b = staging[2 * (size_t)i + 1];
-        q_out[2 * ((size_t)base + i)] = a;
-        q_out[2 * ((size_t)base + i) + 1] = b;
-    }
-    if (fit < stage_n) {
-        queue_full = true;
-        const uint32_t rest = stage_n - fit;
-        if (fit > 0) {
-            for (uint32_t i0 = 0; i0 < rest; i0 += RT_WAVE) {       // ascending: a pass never overwrites a later pass's source
-                uint32_t i = i0 + lane;
-                float4 a = make_float4(0, 0, 0, 0), b = a;
-                if (i < rest) { a = staging[2 * (size_t)(fit + i)]; b = staging[2 * (size_t)(fit + i) + 1]; }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                if (i < rest) { staging[2 * (size_t)i] = a; staging[2 * (size_t)i + 1] = b; }
+    if (lane == leader) base = atomicAdd(lds_counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+    if (!want) return RT_REF_NONE;
+    uint32_t k = base + __popcll(mask & ((1ull << lane) - 1ull));
+    if (k < seg_cap) return blockIdx.x * seg_cap + k;
+    uint32_t j = atomicAdd(&counts[n_seg - 1], 1u);
+    if (j < ovf_cap) return (n_seg - 1) * seg_cap + j;
+    *overflow_flag = 1u;
+    return RT_REF_NONE;
+}
+
+// ---- exact walk for rays with a non-finite component ------------------------------------------------
+// intersect.rs:228-269 in the reference's own order, no pruning.  A candidate with t = NaN ends the walk:
+// nothing can replace it (utils/mod.rs:17).
+__device__ void exact_mesh_hit(const DScene& S, uint32_t root_ref, const Ray& lr, bool& m_have, float& m_t, float& m_u,
+                               float& m_v, uint32_t& m_slot) {
+    uint32_t stk[RT_BVH_STACK_LEN];
+    V3 inv = mk(1.0f / lr.d.x, 1.0f / lr.d.y, 1.0f / lr.d.z);
+    m_have = false; m_t = 0.0f; m_u = 0.0f; m_v = 0.0f; m_slot = 0;
+    uint32_t sp = 0;
+    stk[sp++] = root_ref;
+    while (sp > 0) {
+        const uint32_t ref = stk[--sp];
+        if (ref & RT_REF_LEAF_BIT) {
+            const uint32_t first = ref & RT_REF_SLOT_MASK, cnt = (ref >> RT_REF_COUNT_SHIFT) & 7u;
+            for (uint32_t k = 0; k < cnt; ++k) {
+                const uint32_t slot = first + k;
+                float4 h0 = S.tri_hot[3 * slot], h1 = S.tri_hot[3 * slot + 1], h2 = S.tri_hot[3 * slot + 2];
+                float t, u, v;
+                if (triangle_tuv(mk(h0.x, h0.y, h0.z), mk(h0.w, h1.x, h1.y), mk(h1.z, h1.w, h2.x), lr, t, u, v) &&
+                    closer(m_have, m_t, t)) {
+                    m_have = true; m_t = t; m_u = u; m_v = v; m_slot = slot;
+                }
             }
+            if (m_have && m_t != m_t) return;
+        } else {
+            const float4 n0 = S.nodes[4 * ref], n1 = S.nodes[4 * ref + 1], n2 = S.nodes[4 * ref + 2], n3 = S.nodes[4 * ref + 3];
+            float tl, tr;
+            bool hl = slab(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, lr.o, inv, tl);
+            bool hr = slab(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, lr.o, inv, tr);
+            if (hl && sp < RT_BVH_STACK_LEN) stk[sp++] = __float_as_uint(n3.x);      // left first: right is popped first
+            if (hr && sp < RT_BVH_STACK_LEN) stk[sp++] = __float_as_uint(n3.y);
         }
-        stage_n = rest;
-    } else {
-        stage_n = 0;
     }
+}
+
+// world-space t of an instance's closest local hit: intersect.rs:312-319
+__device__ __forceinline__ float world_t(const DScene& S, const DInstance& inst, const Ray& lr, V3 world_origin, float m_t,
+                                         uint32_t m_slot) {
+    float4 h2 = S.tri_hot[3 * m_slot + 2];
+    V3 fn = mk(h2.y, h2.z, h2.w);
+    V3 p = lr.o + lr.d * m_t;
+    V3 sn = (dot3(fn, lr.d) < 0.0f) ? fn : -fn;
+    return distance3(world_origin, transform34(inst.model, p + sn * 1e-4f));
+}
+
+struct ShadowSpec { bool is_shadow, directional; float limit_world; };
+
+__device__ __forceinline__ ShadowSpec shadow_spec(const DScene& S, const RayRec& rr) {
+    ShadowSpec s;
+    s.is_shadow = (rr.meta & RT_RAY_SHADOW) != 0;
+    s.directional = false;
+    s.limit_world = RT_INF;
+    if (s.is_shadow) {
+        const DLight& L = S.lights[rr.meta & 0xFFu];
+        s.directional = L.pos[3] == 0.0f;
+        if (!s.directional) s.limit_world = distance3(rr.ray.o, ld3(L.world));     // raytracer.rs:177-178
+    }
+    return s;
 }
 
 }  // namespace
 
-// One pass over the rays of one recursion depth.  `level` 0 generates primary rays from pixel
-// indices; other levels read queue[(level + 1) & 1] and all append to queue[level & 1].
-__global__ void __launch_bounds__(RT_BLOCK_THREADS)
-rt_trace_level(const DScene S, const DFrame F, const uint32_t level) {
-    extern __shared__ uint32_t lds_stack[];
+// ======================================================================================================
+// Kernel 0: primary rays (raytracer.rs:30-51) for this shard's pixels -> ray list of depth 0.
+// ======================================================================================================
+__global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_generate(const DFrame F) {
+    __shared__ uint32_t out_n;
+    if (threadIdx.x == 0) out_n = 0;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & (RT_WAVE - 1);
+    const uint32_t gwave = (blockIdx.x * blockDim.x + threadIdx.x) / RT_WAVE;
+    const uint32_t n_waves = gridDim.x * (RT_BLOCK_THREADS / RT_WAVE);
+    for (uint32_t c = gwave; (unsigned long long)c * RT_WAVE < F.n_pixels; c += n_waves) {
+        const uint32_t p = c * RT_WAVE + lane;
+        uint32_t col = 0, row = 0;
+        const bool inside = p < F.n_pixels && pixel_coords(F, p, col, row);
+        RayRec rr;
+        rr.ray.o = rr.ray.d = mk(0, 0, 0);
+        if (inside) rr.ray = primary_ray(F, col, row);
+        rr.throughput = 1.0f;
+        rr.meta = p;
+        uint32_t slot = append_slot(inside, &out_n, F.seg_rays, F.n_seg, F.ray_counts[0], F.ovf_rays, F.overflow, lane);
+        if (slot != RT_REF_NONE) store_rec(F.rays[0], slot, rr);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) F.ray_counts[0][blockIdx.x] = out_n < F.seg_rays ? out_n : F.seg_rays;
+}
+
+// ======================================================================================================
+// Kernel A: per ray, the analytic primitives (scene.rs:129-131) and the root test of every mesh instance.
+// Writes the best analytic candidate to F.best and one BVH work item per instance whose root box the ray
+// enters within the distance that still matters.  Rays with a non-finite component are traced to the
+// end here, in the reference's exact order.
+// ======================================================================================================
+__global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_setup(const DScene S, const DFrame F, const uint32_t level) {
+    extern __shared__ uint32_t lds[];
+    uint32_t* pre = lds;                       // n_seg + 1
+    uint32_t* scratch = lds + F.n_seg + 1;     // blockDim.x
+    __shared__ uint32_t out_n;
+    if (threadIdx.x == 0) out_n = 0;
+    const uint32_t p = level & 1;
+    const uint32_t n_rays = build_prefix(F.ray_counts[p], F.n_seg, F.seg_rays, F.ovf_rays, pre, scratch);
+    const float4* rays = F.rays[p];
+    const uint32_t lane = threadIdx.x & (RT_WAVE - 1);
+    const uint32_t gwave = (blockIdx.x * blockDim.x + threadIdx.x) / RT_WAVE;
+    const uint32_t n_waves = gridDim.x * (RT_BLOCK_THREADS / RT_WAVE);
+
+    for (uint32_t c = gwave; (unsigned long long)c * RT_WAVE < n_rays; c += n_waves) {
+        const uint32_t v = c * RT_WAVE + lane;
+        const bool active = v < n_rays;
+        uint32_t gi = 0;
+        RayRec rr;
+        rr.ray.o = rr.ray.d = mk(0, 0, 0);
+        rr.throughput = 0.0f;
+        rr.meta = 0;
+        if (active) { gi = locate(pre, F.n_seg, F.seg_rays, v); rr = load_rec(rays, gi); }
+        const Ray r = rr.ray;
+        const ShadowSpec ss = shadow_spec(S, rr);
+        const bool ray_finite = finite3(r.o) && finite3(r.d);
+        const bool early = ss.is_shadow && (ss.directional || ray_finite);
+
+        // planes, spheres, triangles: intersect.rs:20-36 per kind, merged as scene.rs:129-131
+        bool have = false; float best_t = 0.0f; uint32_t best_order = 0;
+        bool settled = false;
+        if (active) {
+            {
+                bool g_have = false; float g_t = 0.0f; uint32_t g_i = 0;
+                for (uint32_t i = 0; i < S.n_planes; ++i) {
+                    float t;
+                    if (plane_t(S.planes[i], r, t) && closer(g_have, g_t, t)) { g_have = true; g_t = t; g_i = i; }
+                }
+                if (g_have && closer(have, best_t, g_t)) { have = true; best_t = g_t; best_order = analytic_order(RT_PRIM_PLANE, g_i); }
+            }
+            settled = early && have && (ss.directional || best_t < ss.limit_world);
+            if (!settled) {
+                bool g_have = false; float g_t = 0.0f; uint32_t g_i = 0;
+                for (uint32_t i = 0; i < S.n_spheres; ++i) {
+                    float t;
+                    if (sphere_t(S.spheres[i], r, t) && closer(g_have, g_t, t)) { g_have = true; g_t = t; g_i = i; }
+                }
+                if (g_have && closer(have, best_t, g_t)) { have = true; best_t = g_t; best_order = analytic_order(RT_PRIM_SPHERE, g_i); }
+                settled = early && have && (ss.directional || best_t < ss.limit_world);
+            }
+            if (!settled) {
+                bool g_have = false; float g_t = 0.0f; uint32_t g_i = 0;
+                for (uint32_t i = 0; i < S.n_triangles; ++i) {
+                    const DTriangle& tr = S.triangles[i];
+                    float t, u, w;
+                    if (triangle_tuv(ld3(tr.p0), ld3(tr.e1), ld3(tr.e2), r, t, u, w) && closer(g_have, g_t, t)) {
+                        g_have = true; g_t = t; g_i = i;
+                    }
+                }
+                if (g_have && closer(have, best_t, g_t)) { have = true; best_t = g_t; best_order = analytic_order(RT_PRIM_TRIANGLE, g_i); }
+                settled = early && have && (ss.directional || best_t < ss.limit_world);
+            }
+        }
+
+        // mesh instances in Vec order (scene.rs:133-136)
+        const float o_l1 = fabsf(r.o.x) + fabsf(r.o.y) + fabsf(r.o.z);
+        bool exact_mesh = false;             // exact path: the winner so far is a mesh triangle
+        float ex_t = 0.0f, ex_u = 0.0f, ex_v = 0.0f; uint32_t ex_slot = 0, ex_inst = 0;
+        for (uint32_t ii = 0; ii < S.n_instances; ++ii) {
+            const DInstance& inst = S.instances[ii];
+            bool want_item = false;
+            if (active && !settled && inst.root_ref != RT_REF_NONE && !(have && best_t != best_t)) {
+                Ray lr;
+                lr.o = transform34(inst.model_inverse, r.o);
+                V3 dv = transform34(inst.rotation_scale_inverse, r.d);
+                float dn = sqrtf(dot3(dv, dv));
+                lr.d = mk(dv.x / dn, dv.y / dn, dv.z / dn);                 // glm::normalize, intersect.rs:304-308
+                const bool lr_finite = ray_finite && finite3(lr.o) && finite3(lr.d);
+                if (!lr_finite) {
+                    // reference order, to the end, right here
+                    bool m_have; float m_t, m_u, m_v; uint32_t m_slot;
+                    exact_mesh_hit(S, inst.root_ref, lr, m_have, m_t, m_u, m_v, m_slot);
+                    if (m_have) {
+                        float tw = world_t(S, inst, lr, r.o, m_t, m_slot);
+                        if (closer(have, best_t, tw)) {
+                            have = true; best_t = tw; exact_mesh = true;
+                            ex_t = m_t; ex_u = m_u; ex_v = m_v; ex_slot = m_slot; ex_inst = ii;
+                        }
+                        settled = early && have && (ss.directional || best_t < ss.limit_world);
+                    }
+                } else {
+                    V3 inv = mk(1.0f / lr.d.x, 1.0f / lr.d.y, 1.0f / lr.d.z);
+                    float root_tmin;
+                    bool pass = slab(inst.root_lo[0], inst.root_lo[1], inst.root_lo[2], inst.root_hi[0], inst.root_hi[1],
+                                     inst.root_hi[2], lr.o, inv, root_tmin);
+                    if (pass && inst.prunable) {
+                        // beyond the best analytic hit (or the light) nothing in this mesh can matter; see rt_traverse
+                        float lw = ss.limit_world;
+                        if (have && best_t < lw) lw = best_t;
+                        if (lw < RT_INF) {
+                            float limit = (lw + 2.0f * inst.world_guard + 1.52587890625e-05f * (o_l1 + lw)) * dn * 1.0009765625f;
+                            pass = !(root_tmin > limit * RT_PRUNE_REL + inst.prune_abs);
+                        }
+                    }
+                    want_item = pass;
+                }
+            }
+            uint32_t slot = append_slot(want_item, &out_n, F.seg_items, F.n_seg, F.item_counts, F.ovf_items, F.overflow, lane);
+            if (slot != RT_REF_NONE) F.items[slot] = make_uint2(gi, ii);
+        }
+        // a mesh winner found on the exact path is recorded as a finished work item
+        {
+            uint32_t slot = append_slot(active && exact_mesh, &out_n, F.seg_items, F.n_seg, F.item_counts, F.ovf_items, F.overflow, lane);
+            if (slot != RT_REF_NONE) {
+                F.items[slot] = make_uint2(gi, ex_inst | RT_ITEM_DONE);
+                F.item_results[slot] = make_float4(ex_t, ex_u, ex_v, __uint_as_float(ex_slot));
+                best_order = RT_KEY_MESH | slot;
+            } else if (active && exact_mesh) {
+                have = false;                                              // list overflow: the frame is redone anyway
+            }
+        }
+        if (active) {
+            // finite rays: ordered key, merged with the work items' results by kernel B; rays traced on the exact
+            // path are final here and keep the raw bits of t (which may be NaN)
+            unsigned long long key = RT_KEY_NONE;
+            if (have) key = (ray_finite && !exact_mesh) ? make_key(best_t, best_order)
+                                                        : (((unsigned long long)__float_as_uint(best_t) << 32) | best_order);
+            F.best[gi] = key;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) F.item_counts[blockIdx.x] = out_n < F.seg_items ? out_n : F.seg_items;
+}
+
+// ======================================================================================================
+// Kernel B: BVH traversal of the work items, one (ray, instance) pair per lane, lanes refilled as they
+// finish.  The outcome is that of intersect.rs:228-326 for the pair; how it gets there:
+//  * A node's box is tested when its parent is visited (the parent holds both child boxes), with the
+//    reference's arithmetic, so the set of boxes that "pass" is the reference's.
+//  * Distance pruning: a box whose entry distance lies beyond the best candidate so far (for this pair,
+//    for the ray as a whole, or beyond the light of a shadow ray) by more than the slack cannot hold a
+//    candidate that compares lower.  The slack (RT_PRUNE_REL and the instance's prune_abs) dominates
+//    the rounding error of Moeller-Trumbore's t for the triangle sizes of a `prunable` mesh; other
+//    meshes are walked exactly as the reference walks them.
+//  * Near child first.  The reference resolves equal t by visiting order (utils/mod.rs:17, strict `<`);
+//    triangle slots are numbered in that visiting order, so "lower slot wins a tie" gives the same
+//    winner in any visiting order.
+//  * Shadow rays (raytracer.rs:171-187) only need `t < distance to the light`: the walk stops at the
+//    first candidate that settles it.
+// The per-lane stack lives in LDS: entry e of lane l is stack[e * 64 + l] (child reference) and
+// stack[(entries + e) * 64 + l] (box entry distance).
+// ======================================================================================================
+__global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, const DFrame F, const uint32_t level) {
+    extern __shared__ uint32_t lds[];
+    uint32_t* pre = lds;
+    uint32_t* scratch = lds + F.n_seg + 1;
+    const uint32_t n_items = build_prefix(F.item_counts, F.n_seg, F.seg_items, F.ovf_items, pre, scratch);
     const uint32_t lane = threadIdx.x & (RT_WAVE - 1);
     const uint32_t wave = threadIdx.x / RT_WAVE;
-    uint32_t* stack = lds_stack + wave * (2 * S.stack_entries * RT_WAVE) + lane;
-    const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
-
-    DCounters* C = F.counters;
-    const float4* q_in = F.queue[(level + 1) & 1];
-    float4* q_out = F.queue[level & 1];
-    uint32_t n_in;
-    if (level == 0) {
-        n_in = F.n_pixels;
-    } else {
-        n_in = C->queue_count[(level + 1) & 1];
-        if (n_in > F.queue_capacity) n_in = F.queue_capacity;
-    }
-    float4* spill = F.spill + (size_t)gtid * F.max_depth * 2;
-    uint32_t spill_n = 0;
-
-    uint32_t n_primary = 0, n_shadow = 0, n_reflected = 0, n_transmitted = 0, n_spilled = 0;
-
-    // Input: chunk c is the rays [c * RT_REFILL_CHUNK, (c + 1) * RT_REFILL_CHUNK); wave w of W takes the
-    // chunks w, w + W, w + 2W, ... - neighbouring chunks go to different waves, and nobody touches a
-    // shared cursor (a contended device-wide atomic costs about 10 ns, serialised over all waves).
-    const uint32_t gwave = gtid / RT_WAVE;
+    uint32_t* stack = lds + F.n_seg + 1 + blockDim.x + wave * (2 * S.stack_entries * RT_WAVE) + lane;
+    uint32_t* stack_t = stack + S.stack_entries * RT_WAVE;
+    const uint32_t gwave = (blockIdx.x * blockDim.x + threadIdx.x) / RT_WAVE;
     const uint32_t n_waves = gridDim.x * (RT_BLOCK_THREADS / RT_WAVE);
-    uint32_t my_chunk = gwave;
-    uint32_t chunk_next = 0, chunk_end = 0;     // wave-uniform: what is left of the current chunk
+    const float4* rays = F.rays[level & 1];
+
+    uint32_t my_chunk = gwave, chunk_next = 0, chunk_end = 0;       // wave-uniform
     bool exhausted = false;
 
-    // Output: children are staged in a wave-private buffer and moved to the next depth's queue in
-    // bulk, one atomic per move.  If that queue is full the wave keeps them and traces them itself.
-    float4* staging = F.staging + (size_t)gwave * RT_STAGING_RECORDS * 2;
-    uint32_t stage_n = 0;                       // wave-uniform
-    bool queue_full = false;                    // wave-uniform
-
-#ifdef RT_STATS
-    DbgStats dbg = {0, 0, 0, 0, 0, 0};
-    uint32_t dbg_iters = 0;
-#endif
-    int state = ST_IDLE;
-    RayRec cur;                 // the lane's MAIN ray
-    cur.ray.o = cur.ray.d = mk(0, 0, 0);
-    cur.throughput = 0.0f;
-    cur.meta = 0;
-    // state carried from MAIN to the SHADOW states
-    Hitpoint hit;
-    hit.position = hit.hit_normal = hit.position_for_refraction = mk(0, 0, 0);
-    hit.on_frontside = false;
-    hit.material = 0;
-    V3 color = mk(0, 0, 0);
-    uint32_t light_i = 0;
-    Ray sray;
-    sray.o = sray.d = mk(0, 0, 0);
+    // per-lane state of the pair being walked
+    bool running = false;
+    uint32_t item = 0, gi = 0, ii = 0, sp = 0;
+    Ray lr; lr.o = lr.d = mk(0, 0, 0);
+    V3 inv = mk(0, 0, 0), world_o = mk(0, 0, 0);
+    bool fast = false, early = false, directional = false;
+    float limit = RT_INF, prune_abs = 0.0f, slack_w = 0.0f, limit_world = RT_INF, o_l1 = 0.0f;
+    bool m_have = false; float m_t = 0.0f, m_u = 0.0f, m_v = 0.0f; uint32_t m_slot = 0;
 
     for (;;) {
-        // ---- refill idle lanes: own spilled children first, then the input queue ----------------
-        if (state == ST_IDLE && spill_n > 0) {
-            --spill_n;
-            cur = load_rec(spill, spill_n);
-            state = ST_MAIN;
-        }
-        {
-            bool want = state == ST_IDLE;
-            unsigned long long mask = __ballot(want);
-            if (mask) {
-                const uint32_t asking = __popcll(mask);
-                const uint32_t r = __popcll(mask & ((1ull << lane) - 1ull));
-                // staged children that can no longer go to the next depth's queue come first (newest first)
-                const uint32_t from_stage = queue_full ? (asking < stage_n ? asking : stage_n) : 0u;
-                if (want && r < from_stage) {
-                    cur = load_rec(staging, stage_n - 1 - r);
-                    state = ST_MAIN;
-                    ++n_spilled;
+        const unsigned long long idle_mask = __ballot(!running);
+        const unsigned long long run_mask = ~idle_mask;
+        // ---- refill: once a quarter of the wave is idle, or nobody is walking ---------------------------
+        if (run_mask == 0 || __popcll(idle_mask) >= 16) {
+            if (chunk_next == chunk_end && !exhausted) {
+                if ((unsigned long long)my_chunk * RT_WAVE >= n_items) exhausted = true;
+                else {
+                    chunk_next = my_chunk * RT_WAVE;
+                    chunk_end = (n_items - chunk_next < RT_WAVE) ? n_items : chunk_next + RT_WAVE;
+                    my_chunk += n_waves;
                 }
-                stage_n -= from_stage;
-                if (asking > from_stage) {
-                    if (chunk_next == chunk_end && !exhausted) {
-                        if ((unsigned long long)my_chunk * RT_REFILL_CHUNK >= n_in) {
-                            exhausted = true;
-                        } else {
-                            chunk_next = my_chunk * RT_REFILL_CHUNK;
-                            chunk_end = (n_in - chunk_next < RT_REFILL_CHUNK) ? n_in : chunk_next + RT_REFILL_CHUNK;
-                            my_chunk += n_waves;
+            }
+            const uint32_t avail = chunk_end - chunk_next;
+            if (avail == 0 && run_mask == 0) break;                 // exhausted and nothing in flight
+            const uint32_t asking = __popcll(idle_mask);
+            if (!running) {
+                const uint32_t rank = __popcll(idle_mask & ((1ull << lane) - 1ull));
+                if (rank < avail) {
+                    item = locate(pre, F.n_seg, F.seg_items, chunk_next + rank);
+                    const uint2 it = F.items[item];
+                    if (!(it.y & RT_ITEM_DONE)) {
+                        gi = it.x; ii = it.y;
+                        const RayRec rr = load_rec(rays, gi);
+                        const ShadowSpec ss = shadow_spec(S, rr);
+                        const DInstance& inst = S.instances[ii];
+                        world_o = rr.ray.o;
+                        o_l1 = fabsf(world_o.x) + fabsf(world_o.y) + fabsf(world_o.z);
+                        lr.o = transform34(inst.model_inverse, rr.ray.o);
+                        V3 dv = transform34(inst.rotation_scale_inverse, rr.ray.d);
+                        float dn = sqrtf(dot3(dv, dv));
+                        lr.d = mk(dv.x / dn, dv.y / dn, dv.z / dn);
+                        inv = mk(1.0f / lr.d.x, 1.0f / lr.d.y, 1.0f / lr.d.z);
+                        fast = inst.prunable != 0;
+                        early = ss.is_shadow;
+                        directional = ss.directional;
+                        limit_world = ss.limit_world;
+                        slack_w = 2.0f * inst.world_guard;
+                        prune_abs = inst.prune_abs;
+                        // mesh-local bound on useful t: a hit at world distance w lies at local t = w * dn (up to
+                        // world_guard).  F.best only ever decreases, so any value read here is a valid bound.
+                        limit = RT_INF;
+                        if (fast) {
+                            float lw = limit_world;
+                            const unsigned long long key = F.best[gi];
+                            if (key != RT_KEY_NONE) { float bt = __uint_as_float((uint32_t)(key >> 32)); if (bt < lw) lw = bt; }
+                            if (lw < RT_INF) limit = (lw + slack_w + 1.52587890625e-05f * (o_l1 + lw)) * dn * 1.0009765625f;
+                        }
+                        float root_tmin;
+                        bool pass = slab(inst.root_lo[0], inst.root_lo[1], inst.root_lo[2], inst.root_hi[0], inst.root_hi[1],
+                                         inst.root_hi[2], lr.o, inv, root_tmin);
+                        if (pass && fast && root_tmin > limit * RT_PRUNE_REL + prune_abs) pass = false;
+                        if (pass) {
+                            m_have = false; m_t = 0.0f; m_u = 0.0f; m_v = 0.0f; m_slot = 0;
+                            stack[0] = inst.root_ref;
+                            stack_t[0] = __float_as_uint(root_tmin);
+                            sp = 1;
+                            running = true;
                         }
                     }
-                    const uint32_t avail = chunk_end - chunk_next;
-                    const uint32_t asking2 = asking - from_stage;
-                    if (want && r >= from_stage) {
-                        const uint32_t r2 = r - from_stage;
-                        if (r2 < avail) {
-                            uint32_t idx = chunk_next + r2;
-                            if (level == 0) {
-                                uint32_t col, row;
-                                if (pixel_coords(F, idx, col, row)) {
-                                    cur.ray = primary_ray(F, col, row);
-                                    cur.throughput = 1.0f;
-                                    cur.meta = idx;
-                                    state = ST_MAIN;
-                                }                               // padding pixel: stay idle, ask again
-                            } else {
-                                cur = load_rec(q_in, idx);
-                                state = ST_MAIN;
-                            }
-                        } else if (exhausted && avail == 0) {
-                            state = ST_EMPTY;
+                }
+            }
+            chunk_next += asking < avail ? asking : avail;
+        }
+        // ---- one node per walking lane -----------------------------------------------------------------
+        if (running) {
+            --sp;
+            const uint32_t ref = stack[sp * RT_WAVE];
+            const float entry = __uint_as_float(stack_t[sp * RT_WAVE]);
+            float cut = RT_INF;                                      // boxes entered beyond this cannot matter
+            if (fast) {
+                float lim = (m_have && m_t < limit) ? m_t : limit;
+                cut = lim * RT_PRUNE_REL + prune_abs;
+            }
+            if (!(entry > cut)) {
+                if (ref & RT_REF_LEAF_BIT) {
+                    const uint32_t first = ref & RT_REF_SLOT_MASK;
+                    const uint32_t cnt = (ref >> RT_REF_COUNT_SHIFT) & 7u;
+                    bool improved = false;
+                    for (uint32_t k = 0; k < cnt; ++k) {
+                        const uint32_t slot = first + k;
+                        float4 h0 = S.tri_hot[3 * slot], h1 = S.tri_hot[3 * slot + 1], h2 = S.tri_hot[3 * slot + 2];
+                        float t, u, v;
+                        if (triangle_tuv(mk(h0.x, h0.y, h0.z), mk(h0.w, h1.x, h1.y), mk(h1.z, h1.w, h2.x), lr, t, u, v) &&
+                            (!m_have || t < m_t || (t == m_t && slot < m_slot))) {
+                            m_have = true; m_t = t; m_u = u; m_v = v; m_slot = slot;
+                            improved = true;
                         }
                     }
-                    chunk_next += asking2 < avail ? asking2 : avail;
+                    if (early && improved) {
+                        // would this candidate already prove "shadow"?  The pair's final hit has a local t that is
+                        // not larger, hence a world t that is at most 2 * world_guard larger.
+                        float tw = world_t(S, S.instances[ii], lr, world_o, m_t, m_slot);
+                        if (directional || tw < limit_world - (slack_w + 6.103515625e-05f * (o_l1 + limit_world))) sp = 0;
+                    }
+                } else {
+                    const float4 n0 = S.nodes[4 * ref], n1 = S.nodes[4 * ref + 1], n2 = S.nodes[4 * ref + 2], n3 = S.nodes[4 * ref + 3];
+                    float tl, tr;
+                    bool hl = slab(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, lr.o, inv, tl);
+                    bool hr = slab(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, lr.o, inv, tr);
+                    hl = hl && !(tl > cut);
+                    hr = hr && !(tr > cut);
+                    uint32_t rl = __float_as_uint(n3.x), rr2 = __float_as_uint(n3.y);
+                    // reference order: push left, push right, so that right is popped first (intersect.rs:253-256);
+                    // on the fast path the nearer child is popped first instead
+                    if (fast && tl < tr) {
+                        uint32_t tu = rl; rl = rr2; rr2 = tu;
+                        float tf = tl; tl = tr; tr = tf;
+                        bool tb = hl; hl = hr; hr = tb;
+                    }
+                    if (hl) { stack[sp * RT_WAVE] = rl; stack_t[sp * RT_WAVE] = __float_as_uint(tl); ++sp; }
+                    if (hr) { stack[sp * RT_WAVE] = rr2; stack_t[sp * RT_WAVE] = __float_as_uint(tr); ++sp; }
+                }
+            }
+            if (sp == 0) {
+                // the pair is done: merge its closest hit into the ray's best candidate (scene.rs:133-136)
+                running = false;
+                if (m_have) {
+                    float tw = world_t(S, S.instances[ii], lr, world_o, m_t, m_slot);
+                    F.item_results[item] = make_float4(m_t, m_u, m_v, __uint_as_float(m_slot));
+                    atomicMin(&F.best[gi], make_key(tw, RT_KEY_MESH | item));
                 }
             }
         }
-        if (__all(state == ST_EMPTY)) {
-            // nothing left to trace: hand the staged children over; whatever does not fit stays here
-            if (stage_n > 0 && !queue_full) flush_staging(C, level, F.queue_capacity, q_out, staging, stage_n, queue_full, lane);
-            if (stage_n == 0) break;
-            state = ST_IDLE;
-            continue;
-        }
-        RT_STAT(dbg_iters += (lane == 0) ? 1u : 0u);
+    }
+}
 
-        // ---- trace one ray per busy lane -------------------------------------------------------
-        Closest cl;
-        cl.have = false;
-        {
-            Ray tr = cur.ray;
-            float limit_world = RT_INF;
-            bool directional = false;
-            if (state == ST_SHADOW) {
-                tr = sray;
-                const DLight& L = S.lights[light_i];
-                directional = L.pos[3] == 0.0f;
-                if (!directional) limit_world = distance3(sray.o, ld3(L.world));      // raytracer.rs:177-178
-            }
-            if (state == ST_MAIN || state == ST_SHADOW) trace_scene(S, tr, stack, cl, limit_world, state == ST_SHADOW, directional
-#ifdef RT_STATS
-                                                                    , dbg
-#endif
-                                                                    );
-        }
-        // children produced by this trip round the loop; queued together further down
-        bool emit_r = false, emit_t = false;
+// ======================================================================================================
+// Kernel C: per ray of this depth, what raytrace_impl / shade do once the closest hit is known
+// (raytracer.rs:65-135), except the Phong sum, which has to wait for its shadow rays (kernel D).
+// Shadow rays only record their verdict (raytracer.rs:171-187).
+// ======================================================================================================
+__global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_shade(const DScene S, const DFrame F, const uint32_t level) {
+    extern __shared__ uint32_t lds[];
+    uint32_t* pre = lds;
+    uint32_t* scratch = lds + F.n_seg + 1;
+    __shared__ uint32_t out_rays, out_hits;
+    if (threadIdx.x == 0) { out_rays = 0; out_hits = 0; }
+    const uint32_t p = level & 1, q = p ^ 1;
+    const uint32_t n_rays = build_prefix(F.ray_counts[p], F.n_seg, F.seg_rays, F.ovf_rays, pre, scratch);
+    const float4* rays = F.rays[p];
+    float4* rays_out = F.rays[q];
+    const uint32_t lane = threadIdx.x & (RT_WAVE - 1);
+    const uint32_t gwave = (blockIdx.x * blockDim.x + threadIdx.x) / RT_WAVE;
+    const uint32_t n_waves = gridDim.x * (RT_BLOCK_THREADS / RT_WAVE);
+    uint32_t n_primary = 0, n_shadow = 0, n_reflected = 0, n_transmitted = 0;
+
+    for (uint32_t c = gwave; (unsigned long long)c * RT_WAVE < n_rays; c += n_waves) {
+        const uint32_t v = c * RT_WAVE + lane;
+        const bool active = v < n_rays;
+        uint32_t gi = 0;
+        RayRec cur;
+        cur.ray.o = cur.ray.d = mk(0, 0, 0);
+        cur.throughput = 0.0f;
+        cur.meta = 0;
+        unsigned long long key = RT_KEY_NONE;
+        if (active) { gi = locate(pre, F.n_seg, F.seg_rays, v); cur = load_rec(rays, gi); key = F.best[gi]; }
+        const bool have = key != RT_KEY_NONE;
+        const float best_t = __uint_as_float((uint32_t)(key >> 32));
+        const uint32_t order = (uint32_t)key;
+
+        bool emit_r = false, emit_t = false, emit_hit = false;
         RayRec rec_r, rec_t;
         rec_r.ray.o = rec_r.ray.d = rec_t.ray.o = rec_t.ray.d = mk(0, 0, 0);
         rec_r.throughput = rec_t.throughput = 0.0f;
         rec_r.meta = rec_t.meta = 0;
+        Hitpoint hit;
+        hit.position = hit.hit_normal = hit.position_for_refraction = mk(0, 0, 0);
+        hit.on_frontside = false;
+        hit.material = 0;
+        const uint32_t pixel = cur.meta & RT_META_PIXEL_MASK;
 
-        if (state == ST_MAIN) {
-            const uint32_t pixel = cur.meta & RT_META_PIXEL_MASK;
-            const uint32_t depth = cur.meta >> RT_META_DEPTH_SHIFT;
+        if (active && (cur.meta & RT_RAY_SHADOW)) {
+            // ---- shadow ray: raytracer.rs:171-187 --------------------------------------------------------
+            ++n_shadow;
+            const ShadowSpec ss = shadow_spec(S, cur);
+            const bool is_shadow = have && (ss.directional || best_t < ss.limit_world);
+            const uint32_t hit_slot = __float_as_uint(cur.throughput);
+            F.shadow_flags[q][(size_t)hit_slot * S.n_lights + (cur.meta & 0xFFu)] = is_shadow ? 1 : 0;
+        } else if (active) {
+            // ---- primary / reflected / transmitted ray -----------------------------------------------------
             const uint32_t kind = (cur.meta >> RT_META_KIND_SHIFT) & 1u;
-            if (depth == 0) ++n_primary; else if (kind) ++n_transmitted; else ++n_reflected;
-            if (!cl.have) {
+            if (level == 0) ++n_primary; else if (kind) ++n_transmitted; else ++n_reflected;
+            if (!have) {
                 // raytrace returned None: the caller substitutes the background (main.rs:58-61, raytracer.rs:92,110,112)
                 add_color(F, pixel, background(S, cur.ray.d) * cur.throughput);
-                state = ST_IDLE;
             } else {
+                Closest cl;
+                cl.have = true; cl.t = best_t; cl.inst = RT_INSTANCE_NONE; cl.slot = 0; cl.tl = cl.u = cl.v = 0.0f;
+                if (order & RT_KEY_MESH) {
+                    const uint32_t item = order & ~RT_KEY_MESH;
+                    const float4 res = F.item_results[item];
+                    cl.inst = F.items[item].y & ~RT_ITEM_DONE;
+                    cl.tl = res.x; cl.u = res.y; cl.v = res.z; cl.slot = __float_as_uint(res.w);
+                    cl.prim = ((uint32_t)RT_PRIM_MESH_TRIANGLE << 30) | __float_as_uint(S.tri_cold[3 * cl.slot].w);
+                } else {
+                    cl.prim = ((order >> 29) << 30) | (order & 0x1FFFFFFFu);
+                }
                 hit = finalize_hit(S, cur.ray, cl);
                 const RtMaterial& mat = S.materials[hit.material];
                 const uint32_t mtype = mat.material_type;
                 const bool returns_some = !(mtype == RT_MATERIAL_PHONG && S.n_lights == 0);
                 if (F.aux_flags) {
-                    if (depth == 0) {
+                    if (level == 0) {
                         F.aux_prim[pixel] = cl.prim;
                         F.aux_inst[pixel] = cl.inst;
                         atomicOr(F.aux_flags + pixel, RT_FLAG_HIT | (hit.on_frontside ? RT_FLAG_FRONTSIDE : 0u));
-                    } else if (depth == 1 && returns_some) {
+                    } else if (level == 1 && returns_some) {
                         atomicOr(F.aux_flags + pixel, kind ? RT_FLAG_REFRACTION_HIT : RT_FLAG_REFLECTION_HIT);
                     }
                 }
@@ -774,137 +897,140 @@ rt_trace_level(const DScene S, const DFrame F, const uint32_t level) {
                     float k_transmitted = 1.0f - k_reflected;
                     rec_r.ray.o = hit.position; rec_r.ray.d = rd;
                     rec_r.throughput = cur.throughput * k_reflected;
-                    rec_r.meta = pixel | ((depth + 1) << RT_META_DEPTH_SHIFT);
+                    rec_r.meta = pixel;
                     rec_t.ray.o = hit.position_for_refraction; rec_t.ray.d = td;
                     rec_t.throughput = cur.throughput * k_transmitted;
-                    rec_t.meta = pixel | (1u << RT_META_KIND_SHIFT) | ((depth + 1) << RT_META_DEPTH_SHIFT);
-                    state = ST_IDLE;
-                    if (depth + 1 < F.max_depth) {
+                    rec_t.meta = pixel | (1u << RT_META_KIND_SHIFT);
+                    if (level + 1 < F.max_depth) {
                         emit_r = emit_t = true;
                     } else {
                         // raytrace_impl returns None without tracing (raytracer.rs:66): background of each child
                         add_color(F, pixel, background(S, rd) * rec_r.throughput);
                         add_color(F, pixel, background(S, td) * rec_t.throughput);
                     }
-                } else if (S.n_lights > 0) {
-                    // shade_phong, raytracer.rs:75-84: one shadow ray per light, in order
-                    light_i = 0;
-                    color = mk(0, 0, 0);
-                    state = ST_SHADOW;
-                } else if (mtype == RT_MATERIAL_PHONG) {
-                    // shade() returned None: as a miss
-                    add_color(F, pixel, background(S, cur.ray.d) * cur.throughput);
-                    state = ST_IDLE;
                 } else {
-                    state = ST_SHADOW;       // ReflectAndPhong without lights: goes straight to the finish below
-                    light_i = 0;
-                    color = mk(0, 0, 0);
+                    if (S.n_lights > 0) {
+                        emit_hit = true;                                   // shade_phong, finished by kernel D
+                    } else if (mtype == RT_MATERIAL_PHONG) {
+                        add_color(F, pixel, background(S, cur.ray.d) * cur.throughput);      // shade() returned None: as a miss
+                    }
+                    if (mtype == RT_MATERIAL_REFLECT_AND_PHONG) {
+                        // raytracer.rs:86-94
+                        V3 rd = normalize3(reflected_dir(-cur.ray.d, hit.hit_normal));
+                        rec_r.ray.o = hit.position; rec_r.ray.d = rd;
+                        rec_r.throughput = cur.throughput * 0.8f;          // REFLECTION_DIM_FACTOR
+                        rec_r.meta = pixel;
+                        if (level + 1 < F.max_depth) emit_r = true;
+                        else add_color(F, pixel, background(S, rd) * rec_r.throughput);
+                    }
                 }
             }
-        } else if (state == ST_SHADOW) {
-            // raytracer.rs:171-187 + radiance 137-153 for light `light_i`
-            ++n_shadow;
-            const DLight& L = S.lights[light_i];
-            const RtMaterial& mat = S.materials[hit.material];
-            bool directional = L.pos[3] == 0.0f;
-            bool is_shadow = false;
-            if (cl.have) {
-                if (directional) is_shadow = true;
-                else is_shadow = cl.t < distance3(sray.o, ld3(L.world));
+        }
+
+        // ---- append: hit record, its shadow rays (one per light, raytracer.rs:77-79), child rays ----------
+        const uint32_t hit_slot = append_slot(emit_hit, &out_hits, F.seg_hits, F.n_seg, F.hit_counts[p], F.ovf_hits, F.overflow, lane);
+        if (hit_slot != RT_REF_NONE) {
+            float4* H = F.hits[p] + 3 * (size_t)hit_slot;
+            H[0] = make_float4(hit.position.x, hit.position.y, hit.position.z, __uint_as_float(hit.material));
+            H[1] = make_float4(hit.hit_normal.x, hit.hit_normal.y, hit.hit_normal.z, cur.throughput);
+            H[2] = make_float4(-cur.ray.d.x, -cur.ray.d.y, -cur.ray.d.z, __uint_as_float(pixel | (level == 0 ? RT_HIT_DEPTH0 : 0u)));
+        }
+        for (uint32_t li = 0; li < S.n_lights; ++li) {
+            const bool want = hit_slot != RT_REF_NONE;
+            const uint32_t slot = append_slot(want, &out_rays, F.seg_rays, F.n_seg, F.ray_counts[q], F.ovf_rays, F.overflow, lane);
+            if (slot != RT_REF_NONE) {
+                const DLight& L = S.lights[li];
+                const bool directional = L.pos[3] == 0.0f;
+                V3 dir = directional ? mk(L.pos[0], L.pos[1], L.pos[2]) : ld3(L.world) - hit.position;      // raytracer.rs:158-167
+                RayRec sr;
+                sr.ray.o = hit.position;
+                sr.ray.d = normalize3(dir);
+                sr.throughput = __uint_as_float(hit_slot);
+                sr.meta = RT_RAY_SHADOW | li;
+                store_rec(rays_out, slot, sr);
+            } else if (want) {
+                F.shadow_flags[p][(size_t)hit_slot * S.n_lights + li] = 0;                 // list overflow: frame is redone
             }
-            if (F.aux_flags && is_shadow && light_i < 4 && (cur.meta >> RT_META_DEPTH_SHIFT) == 0)
-                atomicOr(F.aux_flags + (cur.meta & RT_META_PIXEL_MASK), RT_FLAG_SHADOW_LIGHT0 << light_i);
-            V3 l = sray.d;                                     // = get_hitpoint_to_light_unit_vector
-            V3 n = hit.hit_normal;
-            V3 v = -cur.ray.d;
+        }
+        {
+            const uint32_t slot = append_slot(emit_r, &out_rays, F.seg_rays, F.n_seg, F.ray_counts[q], F.ovf_rays, F.overflow, lane);
+            if (slot != RT_REF_NONE) store_rec(rays_out, slot, rec_r);
+        }
+        {
+            const uint32_t slot = append_slot(emit_t, &out_rays, F.seg_rays, F.n_seg, F.ray_counts[q], F.ovf_rays, F.overflow, lane);
+            if (slot != RT_REF_NONE) store_rec(rays_out, slot, rec_t);
+        }
+    }
+
+    // ---- ray statistics: every wave owns a row of F.wave_stats (no atomics) ----------------------------
+    {
+        uint32_t vals[5] = {n_primary + n_shadow + n_reflected + n_transmitted, n_primary, n_shadow, n_reflected, n_transmitted};
+        for (int k = 0; k < 5; ++k) {
+            uint32_t x = vals[k];
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+            if (lane == 0 && x) F.wave_stats[(size_t)gwave * 8 + k] += x;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        F.ray_counts[q][blockIdx.x] = out_rays < F.seg_rays ? out_rays : F.seg_rays;
+        F.hit_counts[p][blockIdx.x] = out_hits < F.seg_hits ? out_hits : F.seg_hits;
+    }
+}
+
+// ======================================================================================================
+// Kernel D: the Phong sum of shade_phong / radiance (raytracer.rs:75-84, 137-153) for the hits of the
+// previous depth, now that their shadow rays have been traced.
+// ======================================================================================================
+__global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_phong(const DScene S, const DFrame F, const uint32_t level) {
+    extern __shared__ uint32_t lds[];
+    uint32_t* pre = lds;
+    uint32_t* scratch = lds + F.n_seg + 1;
+    const uint32_t q = (level & 1) ^ 1;            // parity of the depth whose hits are finished here
+    const uint32_t n_hits = build_prefix(F.hit_counts[q], F.n_seg, F.seg_hits, F.ovf_hits, pre, scratch);
+    const uint32_t lane = threadIdx.x & (RT_WAVE - 1);
+    const uint32_t gwave = (blockIdx.x * blockDim.x + threadIdx.x) / RT_WAVE;
+    const uint32_t n_waves = gridDim.x * (RT_BLOCK_THREADS / RT_WAVE);
+    for (uint32_t c = gwave; (unsigned long long)c * RT_WAVE < n_hits; c += n_waves) {
+        const uint32_t v = c * RT_WAVE + lane;
+        if (v >= n_hits) continue;
+        const uint32_t hs = locate(pre, F.n_seg, F.seg_hits, v);
+        const float4* H = F.hits[q] + 3 * (size_t)hs;
+        const float4 h0 = H[0], h1 = H[1], h2 = H[2];
+        const V3 position = mk(h0.x, h0.y, h0.z), n = mk(h1.x, h1.y, h1.z), view = mk(h2.x, h2.y, h2.z);
+        const RtMaterial& mat = S.materials[__float_as_uint(h0.w)];
+        const float throughput = h1.w;
+        const uint32_t pw = __float_as_uint(h2.w), pixel = pw & RT_META_PIXEL_MASK;
+        V3 color = mk(0, 0, 0);
+        uint32_t shadow_bits = 0;
+        for (uint32_t li = 0; li < S.n_lights; ++li) {
+            const DLight& L = S.lights[li];
+            const bool is_shadow = F.shadow_flags[q][(size_t)hs * S.n_lights + li] != 0;
+            if (is_shadow && li < 4) shadow_bits |= RT_FLAG_SHADOW_LIGHT0 << li;
+            const bool directional = L.pos[3] == 0.0f;
+            V3 l = normalize3(directional ? mk(L.pos[0], L.pos[1], L.pos[2]) : ld3(L.world) - position);   // raytracer.rs:209-220
             V3 rv = reflected_dir(l, n);
             float l_dot_n = fmaxf(dot3(l, n), 0.0f);
-            float r_dot_v = fmaxf(dot3(rv, v), 0.0f);
+            float r_dot_v = fmaxf(dot3(rv, view), 0.0f);
             V3 emissive = ld3(mat.emissive);
             V3 ambient = cmul(ld3(L.ambient), ld3(mat.ambient));
             V3 zero = mk(0.0f, 0.0f, 0.0f);
             V3 diffuse = is_shadow ? zero : cmul(ld3(L.diffuse), ld3(mat.diffuse)) * l_dot_n;
             V3 specular = is_shadow ? zero : cmul(ld3(L.specular), ld3(mat.specular)) * powf(r_dot_v, mat.shininess);
             V3 rad = emissive + ambient + diffuse + specular;
-            color = (light_i == 0) ? rad : color + rad;        // color::add_option
-            ++light_i;
+            color = (li == 0) ? rad : color + rad;                     // color::add_option
         }
-
-        // ---- SHADOW bookkeeping: next light, or finish the shade ---------------------------------
-        if (state == ST_SHADOW) {
-            if (light_i < S.n_lights) {
-                const DLight& L = S.lights[light_i];
-                bool directional = L.pos[3] == 0.0f;
-                V3 dir = directional ? mk(L.pos[0], L.pos[1], L.pos[2]) : ld3(L.world) - hit.position;
-                sray.o = hit.position;
-                sray.d = normalize3(dir);
-            } else {
-                const uint32_t pixel = cur.meta & RT_META_PIXEL_MASK;
-                const uint32_t depth = cur.meta >> RT_META_DEPTH_SHIFT;
-                const RtMaterial& mat = S.materials[hit.material];
-                if (S.n_lights > 0) add_color(F, pixel, color * cur.throughput);
-                state = ST_IDLE;
-                if (mat.material_type == RT_MATERIAL_REFLECT_AND_PHONG) {
-                    // raytracer.rs:86-94
-                    V3 rd = normalize3(reflected_dir(-cur.ray.d, hit.hit_normal));
-                    rec_r.ray.o = hit.position; rec_r.ray.d = rd;
-                    rec_r.throughput = cur.throughput * 0.8f;  // REFLECTION_DIM_FACTOR
-                    rec_r.meta = pixel | ((depth + 1) << RT_META_DEPTH_SHIFT);
-                    if (depth + 1 < F.max_depth) emit_r = true;
-                    else add_color(F, pixel, background(S, rd) * rec_r.throughput);
-                }
-            }
-        }
-
-        // ---- stage the children; move them to the next depth's queue when the buffer fills up ------
-        {
-            unsigned long long mask_r = __ballot(emit_r), mask_t = __ballot(emit_t);
-            uint32_t total = __popcll(mask_r) + __popcll(mask_t);
-            if (total) {
-                unsigned long long lt = (1ull << lane) - 1ull;
-                uint32_t at_r = stage_n + __popcll(mask_r & lt);
-                uint32_t at_t = stage_n + __popcll(mask_r) + __popcll(mask_t & lt);
-                // children that do not fit are kept by this lane (transmitted first, so that the
-                // reflected one is traced first, as in the reference's evaluation order)
-                if (emit_t) {
-                    if (at_t < RT_STAGING_RECORDS) store_rec(staging, at_t, rec_t);
-                    else { store_rec(spill, spill_n, rec_t); ++spill_n; ++n_spilled; }
-                }
-                if (emit_r) {
-                    if (at_r < RT_STAGING_RECORDS) store_rec(staging, at_r, rec_r);
-                    else { store_rec(spill, spill_n, rec_r); ++spill_n; ++n_spilled; }
-                }
-                stage_n = (stage_n + total < RT_STAGING_RECORDS) ? stage_n + total : RT_STAGING_RECORDS;
-                if (!queue_full && stage_n > RT_STAGING_RECORDS - 2 * RT_WAVE)
-                    flush_staging(C, level, F.queue_capacity, q_out, staging, stage_n, queue_full, lane);
-            }
-        }
+        add_color(F, pixel, color * throughput);
+        if (F.aux_flags && (pw & RT_HIT_DEPTH0) && shadow_bits) atomicOr(F.aux_flags + pixel, shadow_bits);
     }
-
-    // ---- ray statistics: every wave owns a row of F.wave_stats (no atomics) ------------------------
-    {
-        uint32_t vals[6] = {n_primary + n_shadow + n_reflected + n_transmitted, n_primary, n_shadow, n_reflected, n_transmitted, n_spilled};
-        for (int k = 0; k < 6; ++k) {
-            uint32_t v = vals[k];
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-            if (lane == 0 && v) F.wave_stats[(size_t)gwave * 8 + k] += v;
-        }
-    }
-#ifdef RT_STATS
-    {
-        uint32_t dv[7] = {dbg.inner, dbg.leaf, dbg.tris, dbg.setups, dbg.rounds, dbg.transitions, dbg_iters};
-        for (int k = 0; k < 7; ++k) {
-            uint32_t v = dv[k];
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-            if (lane == 0 && v) atomicAdd(&C->dbg[level][k], (unsigned long long)v);
-        }
-    }
-#endif
 }
 
-// Resets the count of the queue that the next pass will fill.
-__global__ void rt_next_level(DCounters* C, uint32_t next_level) {
-    C->queue_count[next_level & 1] = 0;
+// Zeroes the counters of the shared overflow segments that the coming depth will fill.
+__global__ void rt_level_reset(const DFrame F, uint32_t level) {
+    const uint32_t p = level & 1, last = F.n_seg - 1;
+    F.ray_counts[p ^ 1][last] = 0;
+    F.item_counts[last] = 0;
+    F.hit_counts[p][last] = 0;
 }
 
 // color.rs:42-52 + canvas layout.  One thread per local pixel.
@@ -973,28 +1099,39 @@ __global__ void rt_assemble(const uint8_t* gathered, uint8_t* frame, uint32_t wi
 
 // ---- launch wrappers (called from rt_api.hip) ----------------------------------------------------
 
-static size_t trace_lds_bytes(uint32_t stack_entries) {
-    // two words per stack entry (child reference, box entry distance), one column per lane
-    return (size_t)(RT_BLOCK_THREADS / RT_WAVE) * 2 * stack_entries * RT_WAVE * sizeof(uint32_t);
+static size_t list_lds_bytes(uint32_t n_seg) { return (size_t)(n_seg + 1 + RT_BLOCK_THREADS) * sizeof(uint32_t); }
+
+static size_t traverse_lds_bytes(uint32_t n_seg, uint32_t stack_entries) {
+    // prefix table + two words per stack entry (child reference, box entry distance), one column per lane
+    return list_lds_bytes(n_seg) + (size_t)(RT_BLOCK_THREADS / RT_WAVE) * 2 * stack_entries * RT_WAVE * sizeof(uint32_t);
 }
 
-// Resident blocks of the trace kernel per compute unit (registers and the LDS stacks decide).
-extern "C" int rt_query_trace_blocks_per_cu(uint32_t stack_entries) {
+// Resident blocks of the traversal kernel per compute unit (registers and the LDS stacks decide).
+extern "C" int rt_query_traverse_blocks_per_cu(uint32_t n_seg, uint32_t stack_entries) {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, rt_trace_level, RT_BLOCK_THREADS, trace_lds_bytes(stack_entries)) != hipSuccess)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, rt_traverse, RT_BLOCK_THREADS, traverse_lds_bytes(n_seg, stack_entries)) != hipSuccess)
         return -1;
     return n;
 }
 
-extern "C" hipError_t rt_launch_trace_level(const DScene* S, const DFrame* F, uint32_t level, uint32_t blocks,
-                                            hipStream_t stream) {
-    size_t lds = trace_lds_bytes(S->stack_entries);
-    hipLaunchKernelGGL(rt_trace_level, dim3(blocks), dim3(RT_BLOCK_THREADS), lds, stream, *S, *F, level);
+extern "C" hipError_t rt_launch_generate(const DFrame* F, uint32_t blocks, hipStream_t stream) {
+    hipLaunchKernelGGL(rt_generate, dim3(blocks), dim3(RT_BLOCK_THREADS), 0, stream, *F);
     return hipGetLastError();
 }
 
-extern "C" hipError_t rt_launch_next_level(DCounters* C, uint32_t next_level, hipStream_t stream) {
-    hipLaunchKernelGGL(rt_next_level, dim3(1), dim3(1), 0, stream, C, next_level);
+// One recursion depth: A, B, C and (from depth 1 on) D.  `blocks` is the grid of the list-producing
+// kernels (F->n_seg - 1), `traverse_blocks` that of the BVH walk.
+extern "C" hipError_t rt_launch_level(const DScene* S, const DFrame* F, uint32_t level, uint32_t blocks,
+                                      uint32_t traverse_blocks, hipStream_t stream) {
+    const size_t lds = list_lds_bytes(F->n_seg);
+    hipLaunchKernelGGL(rt_level_reset, dim3(1), dim3(1), 0, stream, *F, level);
+    hipLaunchKernelGGL(rt_setup, dim3(blocks), dim3(RT_BLOCK_THREADS), lds, stream, *S, *F, level);
+    if (S->n_instances > 0)
+        hipLaunchKernelGGL(rt_traverse, dim3(traverse_blocks), dim3(RT_BLOCK_THREADS), traverse_lds_bytes(F->n_seg, S->stack_entries),
+                           stream, *S, *F, level);
+    hipLaunchKernelGGL(rt_shade, dim3(blocks), dim3(RT_BLOCK_THREADS), lds, stream, *S, *F, level);
+    if (level > 0 && S->n_lights > 0)
+        hipLaunchKernelGGL(rt_phong, dim3(blocks), dim3(RT_BLOCK_THREADS), lds, stream, *S, *F, level);
     return hipGetLastError();
 }
 
