@@ -418,7 +418,7 @@ static int ensure_frame(RtScene* s, const Geometry& g, uint32_t max_depth, bool 
             (rc = frame_alloc(s, f.n_seg, &f.ray_counts[0])) || (rc = frame_alloc(s, f.n_seg, &f.ray_counts[1])) ||
             (rc = frame_alloc(s, ray_slots, &f.best)) ||
             (rc = frame_alloc(s, item_slots, &f.items)) || (rc = frame_alloc(s, item_slots, &f.item_results)) ||
-            (rc = frame_alloc(s, f.n_seg, &f.item_counts)) ||
+            (rc = frame_alloc(s, f.n_seg, &f.item_counts)) || (rc = frame_alloc(s, RT_MAX_DEPTH_LIMIT + 2, &f.chunk_counter)) ||
             (rc = frame_alloc(s, 3 * hit_slots, &f.hits[0])) || (rc = frame_alloc(s, 3 * hit_slots, &f.hits[1])) ||
             (rc = frame_alloc(s, f.n_seg, &f.hit_counts[0])) || (rc = frame_alloc(s, f.n_seg, &f.hit_counts[1])) ||
             (rc = frame_alloc(s, flag_bytes, &f.shadow_flags[0])) || (rc = frame_alloc(s, flag_bytes, &f.shadow_flags[1])) ||
@@ -462,6 +462,7 @@ static int enqueue_frame(RtScene* s, const RtRenderParams* p, bool sharded, bool
     HIP_TRY(hipMemsetAsync(f.poison, 0, (size_t)g.n_pixels * sizeof(unsigned int), stream));
     HIP_TRY(hipMemsetAsync(f.wave_stats, 0, s->stats_words * sizeof(unsigned int), stream));
     HIP_TRY(hipMemsetAsync(f.ray_counts[0], 0, f.n_seg * sizeof(unsigned int), stream));
+    HIP_TRY(hipMemsetAsync(f.chunk_counter, 0, (RT_MAX_DEPTH_LIMIT + 2) * sizeof(unsigned int), stream));
     if (aux) HIP_TRY(hipMemsetAsync(f.aux_flags, 0, (size_t)g.n_pixels * sizeof(unsigned int), stream));
     HIP_TRY(hipEventRecord(s->ev_trace_start, stream));
     HIP_TRY(rt_launch_generate(&f, s->list_blocks, stream));
@@ -616,6 +617,19 @@ extern "C" int rt_debug_last_spilled(RtScene* s, uint32_t* out) {
     return RT_OK;
 }
 
+
+#ifdef RT_STATS
+// diagnostic build: the BVH work items of the last traversal launch and the per-block counts
+extern "C" int rt_debug_items(RtScene* s, uint2* items, unsigned int* counts, uint32_t* geometry /* n_seg, seg_items, ovf_items */) {
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const DFrame& f = s->f;
+    geometry[0] = f.n_seg; geometry[1] = f.seg_items; geometry[2] = f.ovf_items;
+    if (items) HIP_TRY(hipMemcpy(items, f.items, ((size_t)(f.n_seg - 1) * f.seg_items + f.ovf_items) * sizeof(uint2), hipMemcpyDeviceToHost));
+    if (counts) HIP_TRY(hipMemcpy(counts, f.item_counts, f.n_seg * sizeof(unsigned int), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+#endif
 
 extern "C" const char* rt_last_error(void) { return g_error; }
 

@@ -116,6 +116,7 @@ struct DFrame {
     uint2* items;                    // BVH work items: (ray slot, instance | flags)
     float4* item_results;            // per item: local t, u, v, bits triangle slot
     unsigned int* item_counts;       // [n_seg]
+    unsigned int* chunk_counter;     // [RT_MAX_DEPTH_LIMIT + 2] input chunks of the BVH walk handed out so far, per depth
     float4* hits[2];                 // Phong-shaded hits waiting for their shadow rays, 3 float4 each
     unsigned int* hit_counts[2];     // [n_seg]
     unsigned char* shadow_flags[2];  // [hit slots][n_lights]

@@ -29,6 +29,9 @@
 #include <hip/hip_runtime.h>
 
 #include "rt_device.h"
+#ifdef RT_STATS
+#include <cstdlib>
+#endif
 
 #define RT_BLOCK_THREADS 256
 #define RT_WAVE 64
@@ -650,6 +653,15 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_setup(const DScene S, con
 // The per-lane stack lives in LDS: entry e of lane l is stack[e * 64 + l] (child reference) and
 // stack[(entries + e) * 64 + l] (box entry distance).
 // ======================================================================================================
+#ifdef RT_STATS
+// Diagnostic build: per wave of the last rt_traverse launch: cycles, rounds, refill cycles, refills, cycles and
+// count of rounds in which some lane tested a leaf, cycles and count of the other rounds, sum of walking lanes.
+__device__ unsigned long long g_wave_timing[8192 * 10];
+extern "C" hipError_t rt_debug_wave_timing(unsigned long long* out, size_t n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_timing), n * sizeof(unsigned long long));
+}
+#endif
+
 __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, const DFrame F, const uint32_t level) {
     extern __shared__ uint32_t lds[];
     uint32_t* pre = lds;
@@ -657,35 +669,99 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
     const uint32_t n_items = build_prefix(F.item_counts, F.n_seg, F.seg_items, F.ovf_items, pre, scratch);
     const uint32_t lane = threadIdx.x & (RT_WAVE - 1);
     const uint32_t wave = threadIdx.x / RT_WAVE;
-    uint32_t* stack = lds + F.n_seg + 1 + blockDim.x + wave * (2 * S.stack_entries * RT_WAVE) + lane;
+    uint32_t* wave_stack = lds + F.n_seg + 1 + blockDim.x + wave * (2 * S.stack_entries * RT_WAVE);
+    uint32_t* stack = wave_stack + lane;
     uint32_t* stack_t = stack + S.stack_entries * RT_WAVE;
+    // one record per lane for the pair that lane started: {key lo = triangle slot, key hi = bits of local t,
+    // walkers still at work on the pair, "shadow proven"}; 16-byte aligned
+    uint32_t* recs = lds + ((F.n_seg + 1 + blockDim.x + (blockDim.x / RT_WAVE) * (2 * S.stack_entries * RT_WAVE) + 3u) & ~3u) +
+                     wave * (4 * RT_WAVE);
+    uint32_t* donor_list = scratch + wave * RT_WAVE;               // free again once the prefix table is built
     const uint32_t gwave = (blockIdx.x * blockDim.x + threadIdx.x) / RT_WAVE;
     const uint32_t n_waves = gridDim.x * (RT_BLOCK_THREADS / RT_WAVE);
     const float4* rays = F.rays[level & 1];
 
+    // Input is handed out in chunks of 64 pairs: every wave starts with the chunk of its own index, further ones
+    // come from a counter in device memory (one atomic per 64 pairs), so that waves with light pairs take more.
+    // With less than 64 pairs per wave the chunks shrink, so that every wave gets some and shares the long ones.
+    const bool one_chunk_each = (unsigned long long)n_waves * RT_WAVE >= n_items;
+    const uint32_t chunk_size = one_chunk_each ? (n_items + n_waves - 1) / n_waves : RT_WAVE;
     uint32_t my_chunk = gwave, chunk_next = 0, chunk_end = 0;       // wave-uniform
     bool exhausted = false;
 
-    // per-lane state of the pair being walked
-    bool running = false;
-    uint32_t item = 0, gi = 0, ii = 0, sp = 0;
+    // per-lane state of the walk
+    bool running = false;           // walking a subtree of a pair
+    bool pending = false;           // walk finished, its part in the pair's result not yet settled
+    uint32_t item = 0, gi = 0, ii = 0, sp = 0, base = 0, owner = lane;
     Ray lr; lr.o = lr.d = mk(0, 0, 0);
     V3 inv = mk(0, 0, 0), world_o = mk(0, 0, 0);
     bool fast = false, early = false, directional = false;
-    float limit = RT_INF, prune_abs = 0.0f, slack_w = 0.0f, limit_world = RT_INF, o_l1 = 0.0f;
+    float limit = RT_INF, prune_abs = 0.0f, slack_w = 0.0f, limit_world = RT_INF, o_l1 = 0.0f, inv_dn = 0.0f;
     bool m_have = false; float m_t = 0.0f, m_u = 0.0f, m_v = 0.0f; uint32_t m_slot = 0;
+#ifdef RT_STATS
+    uint32_t dbg_steps = 0;
+    unsigned long long tm[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long t_begin = clock64();
+#endif
 
     for (;;) {
         const unsigned long long idle_mask = __ballot(!running);
         const unsigned long long run_mask = ~idle_mask;
-        // ---- refill: once a quarter of the wave is idle, or nobody is walking ---------------------------
-        if (run_mask == 0 || __popcll(idle_mask) >= 16) {
+        const bool out_of_input = exhausted && chunk_next == chunk_end;
+#ifdef RT_STATS
+        const unsigned long long t_round = clock64();
+        tm[1] += 1;
+        tm[8] += __popcll(run_mask);
+        bool serviced = false;
+#endif
+        // ---- sharing, part 1: once this wave has no more input, idle lanes take over the oldest pending subtree
+        // of lanes that are still walking, so that one long walk does not keep 63 lanes (and the kernel) waiting
+        bool can_give = false;
+        unsigned long long give_mask = 0;
+        if (out_of_input && idle_mask != 0 && run_mask != 0) {
+            can_give = running && fast && sp - base >= 2 && !(stack[base * RT_WAVE] & RT_REF_LEAF_BIT);
+            give_mask = __ballot(can_give);
+        }
+        // ---- service: once a quarter of the wave is idle, nobody is walking, or there is something to share ---
+        if (run_mask == 0 || __popcll(idle_mask) >= 16 || give_mask != 0) {
+#ifdef RT_STATS
+            serviced = true;
+#endif
+            // (1) finished walkers leave their pair; the last one to leave merges the pair's closest hit into the
+            // ray's best candidate (scene.rs:133-136).  Every walker has merged its own closest hit into the
+            // pair's record by (t, slot), the order a single walker applies.
+            if (pending) {
+                pending = false;
+                if (atomicSub(&recs[4 * owner + 2], 1u) == 1u) {
+                    const uint32_t win_slot = ((volatile uint32_t*)recs)[4 * owner];
+                    if (((volatile uint32_t*)recs)[4 * owner + 1] != 0xFFFFFFFFu) {
+                        if (!(m_have && m_slot == win_slot)) {
+                            // another walker found it: the test is a pure function of ray and triangle
+                            const float4 h0 = S.tri_hot[3 * win_slot], h1 = S.tri_hot[3 * win_slot + 1], h2 = S.tri_hot[3 * win_slot + 2];
+                            triangle_tuv(mk(h0.x, h0.y, h0.z), mk(h0.w, h1.x, h1.y), mk(h1.z, h1.w, h2.x), lr, m_t, m_u, m_v);
+                            m_slot = win_slot;
+                        }
+                        float tw = world_t(S, S.instances[ii], lr, world_o, m_t, m_slot);
+                        F.item_results[item] = make_float4(m_t, m_u, m_v, __uint_as_float(m_slot));
+                        atomicMin(&F.best[gi], make_key(tw, RT_KEY_MESH | item));
+                    }
+                }
+            }
+            // (2) new pairs from the input
             if (chunk_next == chunk_end && !exhausted) {
-                if ((unsigned long long)my_chunk * RT_WAVE >= n_items) exhausted = true;
+                if (my_chunk == 0xFFFFFFFFu) {
+                    uint32_t taken = 0;
+                    if (!one_chunk_each) {
+                        if (lane == 0) taken = atomicAdd(&F.chunk_counter[level], 1u);
+                        taken = __builtin_amdgcn_readfirstlane(taken);
+                    }
+                    my_chunk = n_waves + taken;
+                }
+                if ((unsigned long long)my_chunk * chunk_size >= n_items) exhausted = true;
                 else {
-                    chunk_next = my_chunk * RT_WAVE;
-                    chunk_end = (n_items - chunk_next < RT_WAVE) ? n_items : chunk_next + RT_WAVE;
-                    my_chunk += n_waves;
+                    chunk_next = my_chunk * chunk_size;
+                    chunk_end = (n_items - chunk_next < chunk_size) ? n_items : chunk_next + chunk_size;
+                    my_chunk = 0xFFFFFFFFu;                          // the next one is asked for when it is needed
                 }
             }
             const uint32_t avail = chunk_end - chunk_next;
@@ -696,6 +772,9 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
                 if (rank < avail) {
                     item = locate(pre, F.n_seg, F.seg_items, chunk_next + rank);
                     const uint2 it = F.items[item];
+#ifdef RT_STATS
+                    F.items[item].x = 0;
+#endif
                     if (!(it.y & RT_ITEM_DONE)) {
                         gi = it.x; ii = it.y;
                         const RayRec rr = load_rec(rays, gi);
@@ -708,6 +787,7 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
                         float dn = sqrtf(dot3(dv, dv));
                         lr.d = mk(dv.x / dn, dv.y / dn, dv.z / dn);
                         inv = mk(1.0f / lr.d.x, 1.0f / lr.d.y, 1.0f / lr.d.z);
+                        inv_dn = 1.0f / dn;
                         fast = inst.prunable != 0;
                         early = ss.is_shadow;
                         directional = ss.directional;
@@ -731,29 +811,110 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
                             m_have = false; m_t = 0.0f; m_u = 0.0f; m_v = 0.0f; m_slot = 0;
                             stack[0] = inst.root_ref;
                             stack_t[0] = __float_as_uint(root_tmin);
-                            sp = 1;
+                            sp = 1; base = 0;
+                            owner = lane;
+                            recs[4 * lane] = 0xFFFFFFFFu; recs[4 * lane + 1] = 0xFFFFFFFFu;
+                            recs[4 * lane + 2] = 1u; recs[4 * lane + 3] = 0u;
                             running = true;
                         }
                     }
                 }
             }
             chunk_next += asking < avail ? asking : avail;
+            // (3) sharing, part 2 (no input was left, so the idle lanes are still idle)
+            if (give_mask) {
+                const uint32_t n_idle = __popcll(idle_mask), n_give = __popcll(give_mask);
+                const uint32_t n = n_idle < n_give ? n_idle : n_give;
+                const uint32_t give_rank = __popcll(give_mask & ((1ull << lane) - 1ull));
+                const uint32_t idle_rank = __popcll(idle_mask & ((1ull << lane) - 1ull));
+                const bool giving = can_give && give_rank < n;
+                const bool taking = !running && idle_rank < n;
+                if (giving) {
+                    donor_list[give_rank] = lane;
+                    atomicAdd(&recs[4 * owner + 2], 1u);
+                }
+                uint32_t src = lane;
+                if (taking) src = donor_list[idle_rank];
+                const uint32_t flags = (fast ? 1u : 0u) | (early ? 2u : 0u) | (directional ? 4u : 0u);
+                const float ox = __shfl(lr.o.x, src), oy = __shfl(lr.o.y, src), oz = __shfl(lr.o.z, src);
+                const float dx = __shfl(lr.d.x, src), dy = __shfl(lr.d.y, src), dz = __shfl(lr.d.z, src);
+                const float wx = __shfl(world_o.x, src), wy = __shfl(world_o.y, src), wz = __shfl(world_o.z, src);
+                const float s_limit = __shfl(limit, src), s_prune = __shfl(prune_abs, src), s_slack = __shfl(slack_w, src);
+                const float s_lw = __shfl(limit_world, src), s_l1 = __shfl(o_l1, src), s_idn = __shfl(inv_dn, src);
+                const uint32_t s_item = __shfl(item, src), s_gi = __shfl(gi, src), s_ii = __shfl(ii, src);
+                const uint32_t s_owner = __shfl(owner, src), s_flags = __shfl(flags, src), s_base = __shfl(base, src);
+                if (taking) {
+                    lr.o = mk(ox, oy, oz); lr.d = mk(dx, dy, dz); world_o = mk(wx, wy, wz);
+                    inv = mk(1.0f / lr.d.x, 1.0f / lr.d.y, 1.0f / lr.d.z);
+                    limit = s_limit; prune_abs = s_prune; slack_w = s_slack; limit_world = s_lw; o_l1 = s_l1; inv_dn = s_idn;
+                    item = s_item; gi = s_gi; ii = s_ii; owner = s_owner;
+                    fast = (s_flags & 1u) != 0; early = (s_flags & 2u) != 0; directional = (s_flags & 4u) != 0;
+                    m_have = false; m_t = 0.0f; m_u = 0.0f; m_v = 0.0f; m_slot = 0;
+                    stack[0] = wave_stack[s_base * RT_WAVE + src];
+                    stack_t[0] = wave_stack[(S.stack_entries + s_base) * RT_WAVE + src];
+                    sp = 1; base = 0;
+                    running = true;
+                }
+                if (giving) ++base;
+            }
         }
+#ifdef RT_STATS
+        const unsigned long long t_walk = clock64();
+        if (serviced) { tm[9] += t_walk - t_round; }
+        unsigned long long leaf_lanes = 0;
+#endif
         // ---- one node per walking lane -----------------------------------------------------------------
         if (running) {
+#ifdef RT_STATS
+            ++dbg_steps;
+            leaf_lanes = __ballot((stack[(sp - 1) * RT_WAVE] & RT_REF_LEAF_BIT) != 0);
+#endif
             --sp;
             const uint32_t ref = stack[sp * RT_WAVE];
             const float entry = __uint_as_float(stack_t[sp * RT_WAVE]);
+            const uint32_t pair_t = ((volatile uint32_t*)recs)[4 * owner + 1];     // closest hit any walker of the pair has
+            const uint32_t pair_done = ((volatile uint32_t*)recs)[4 * owner + 3];
             float cut = RT_INF;                                      // boxes entered beyond this cannot matter
             if (fast) {
                 float lim = (m_have && m_t < limit) ? m_t : limit;
+                if (pair_t != 0xFFFFFFFFu && __uint_as_float(pair_t) < lim) lim = __uint_as_float(pair_t);
                 cut = lim * RT_PRUNE_REL + prune_abs;
             }
-            if (!(entry > cut)) {
+#ifdef RT_STATS
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            tm[4] += clock64() - t_walk;        // pop
+#endif
+            if (pair_done) sp = base;                                // another walker has proven the shadow
+            else if (!(entry > cut)) {
                 if (ref & RT_REF_LEAF_BIT) {
                     const uint32_t first = ref & RT_REF_SLOT_MASK;
                     const uint32_t cnt = (ref >> RT_REF_COUNT_SHIFT) & 7u;
                     bool improved = false;
+#ifdef RT_STATS
+                    const unsigned long long tl0 = clock64();
+                    float4 h[RT_LEAF_TRIANGLES][3];
+#pragma unroll
+                    for (uint32_t k = 0; k < RT_LEAF_TRIANGLES; ++k) {
+                        const uint32_t slot = first + (k < cnt ? k : (cnt ? cnt - 1 : 0));
+                        if (cnt) { h[k][0] = S.tri_hot[3 * slot]; h[k][1] = S.tri_hot[3 * slot + 1]; h[k][2] = S.tri_hot[3 * slot + 2]; }
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    const unsigned long long tl1 = clock64();
+#pragma unroll
+                    for (uint32_t k = 0; k < RT_LEAF_TRIANGLES; ++k) {
+                        const uint32_t slot = first + k;
+                        float t, u, v;
+                        if (k < cnt &&
+                            triangle_tuv(mk(h[k][0].x, h[k][0].y, h[k][0].z), mk(h[k][0].w, h[k][1].x, h[k][1].y),
+                                         mk(h[k][1].z, h[k][1].w, h[k][2].x), lr, t, u, v) &&
+                            (!m_have || t < m_t || (t == m_t && slot < m_slot))) {
+                            m_have = true; m_t = t; m_u = u; m_v = v; m_slot = slot;
+                            improved = true;
+                        }
+                    }
+                    const unsigned long long tl2 = clock64();
+                    tm[6] += tl1 - tl0; tm[7] += tl2 - tl1;
+#else
                     for (uint32_t k = 0; k < cnt; ++k) {
                         const uint32_t slot = first + k;
                         float4 h0 = S.tri_hot[3 * slot], h1 = S.tri_hot[3 * slot + 1], h2 = S.tri_hot[3 * slot + 2];
@@ -764,14 +925,26 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
                             improved = true;
                         }
                     }
-                    if (early && improved) {
-                        // would this candidate already prove "shadow"?  The pair's final hit has a local t that is
-                        // not larger, hence a world t that is at most 2 * world_guard larger.
-                        float tw = world_t(S, S.instances[ii], lr, world_o, m_t, m_slot);
-                        if (directional || tw < limit_world - (slack_w + 6.103515625e-05f * (o_l1 + limit_world))) sp = 0;
+#endif
+                    if (improved) {
+                        atomicMin((unsigned long long*)&recs[4 * owner], make_key(m_t, m_slot));
+                        // Does this candidate already prove "shadow"?  The pair's final hit has a local t that is not
+                        // larger, and a hit at local t lies within world_guard of world distance t / dn.
+                        if (early && (directional || m_t * inv_dn < limit_world - (1.5f * slack_w + 6.103515625e-05f * (o_l1 + limit_world)))) {
+                            sp = base;
+                            recs[4 * owner + 3] = 1u;
+                        }
                     }
                 } else {
+#ifdef RT_STATS
+                    const unsigned long long ti0 = clock64();
+#endif
                     const float4 n0 = S.nodes[4 * ref], n1 = S.nodes[4 * ref + 1], n2 = S.nodes[4 * ref + 2], n3 = S.nodes[4 * ref + 3];
+#ifdef RT_STATS
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    const unsigned long long ti1 = clock64();
+                    tm[2] += ti1 - ti0;          // node fetch
+#endif
                     float tl, tr;
                     bool hl = slab(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, lr.o, inv, tl);
                     bool hr = slab(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, lr.o, inv, tr);
@@ -787,19 +960,33 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
                     }
                     if (hl) { stack[sp * RT_WAVE] = rl; stack_t[sp * RT_WAVE] = __float_as_uint(tl); ++sp; }
                     if (hr) { stack[sp * RT_WAVE] = rr2; stack_t[sp * RT_WAVE] = __float_as_uint(tr); ++sp; }
+#ifdef RT_STATS
+                    tm[3] += clock64() - ti1;    // box tests and pushes
+#endif
                 }
             }
-            if (sp == 0) {
-                // the pair is done: merge its closest hit into the ray's best candidate (scene.rs:133-136)
-                running = false;
-                if (m_have) {
-                    float tw = world_t(S, S.instances[ii], lr, world_o, m_t, m_slot);
-                    F.item_results[item] = make_float4(m_t, m_u, m_v, __uint_as_float(m_slot));
-                    atomicMin(&F.best[gi], make_key(tw, RT_KEY_MESH | item));
-                }
+            if (sp == base) {
+                running = false;                                     // settled in the next service phase
+                pending = true;
+#ifdef RT_STATS
+                dbg_steps = 0;
+#endif
             }
         }
+#ifdef RT_STATS
+        {
+            const unsigned long long t_end = clock64();
+            leaf_lanes = __shfl(leaf_lanes, __ffsll((long long)run_mask) - 1 < 0 ? 0 : __ffsll((long long)run_mask) - 1);
+            if (run_mask) {
+                if (leaf_lanes) { tm[5] += 1; }
+            }
+        }
+#endif
     }
+#ifdef RT_STATS
+    tm[0] = clock64() - t_begin;
+    if (lane == 0 && gwave < 8192) for (int k = 0; k < 10; ++k) g_wave_timing[gwave * 10 + k] = tm[k];
+#endif
 }
 
 // ======================================================================================================
@@ -1102,8 +1289,10 @@ __global__ void rt_assemble(const uint8_t* gathered, uint8_t* frame, uint32_t wi
 static size_t list_lds_bytes(uint32_t n_seg) { return (size_t)(n_seg + 1 + RT_BLOCK_THREADS) * sizeof(uint32_t); }
 
 static size_t traverse_lds_bytes(uint32_t n_seg, uint32_t stack_entries) {
-    // prefix table + two words per stack entry (child reference, box entry distance), one column per lane
-    return list_lds_bytes(n_seg) + (size_t)(RT_BLOCK_THREADS / RT_WAVE) * 2 * stack_entries * RT_WAVE * sizeof(uint32_t);
+    // prefix table and scan scratch; two words per stack entry (child reference, box entry distance), one column
+    // per lane; then, 16-byte aligned, one 16-byte pair record per lane
+    return list_lds_bytes(n_seg) + (size_t)(RT_BLOCK_THREADS / RT_WAVE) * 2 * stack_entries * RT_WAVE * sizeof(uint32_t) + 16 +
+           (size_t)RT_BLOCK_THREADS * 16;
 }
 
 // Resident blocks of the traversal kernel per compute unit (registers and the LDS stacks decide).
@@ -1124,11 +1313,18 @@ extern "C" hipError_t rt_launch_generate(const DFrame* F, uint32_t blocks, hipSt
 extern "C" hipError_t rt_launch_level(const DScene* S, const DFrame* F, uint32_t level, uint32_t blocks,
                                       uint32_t traverse_blocks, hipStream_t stream) {
     const size_t lds = list_lds_bytes(F->n_seg);
+#ifdef RT_STATS
+    const char* stop = getenv("RT_DEBUG_STOP_LEVEL");           // keep the lists of that depth as rt_traverse left them
+    if (stop && level > (uint32_t)atoi(stop)) return hipSuccess;
+#endif
     hipLaunchKernelGGL(rt_level_reset, dim3(1), dim3(1), 0, stream, *F, level);
     hipLaunchKernelGGL(rt_setup, dim3(blocks), dim3(RT_BLOCK_THREADS), lds, stream, *S, *F, level);
     if (S->n_instances > 0)
         hipLaunchKernelGGL(rt_traverse, dim3(traverse_blocks), dim3(RT_BLOCK_THREADS), traverse_lds_bytes(F->n_seg, S->stack_entries),
                            stream, *S, *F, level);
+#ifdef RT_STATS
+    if (stop && level == (uint32_t)atoi(stop)) return hipGetLastError();
+#endif
     hipLaunchKernelGGL(rt_shade, dim3(blocks), dim3(RT_BLOCK_THREADS), lds, stream, *S, *F, level);
     if (level > 0 && S->n_lights > 0)
         hipLaunchKernelGGL(rt_phong, dim3(blocks), dim3(RT_BLOCK_THREADS), lds, stream, *S, *F, level);

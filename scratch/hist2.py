@@ -1,0 +1,23 @@
+import sys, os, ctypes as C
+sys.path.insert(0, '.')
+import numpy as np
+from rust_raytracer_amd import meshes, native
+native.LIB_PATH = os.path.abspath('scratch/librt_hip_stats.so')
+md = meshes.ensure_model_dir()
+host = native.HostScene.load('scenes/reflective_bunnies.json', md)
+host.resize_screen(1920, 1080)
+dev = native.DeviceScene(host.desc(), 0)
+m, w, h = host.camera(); dev.set_camera(m, w, h)
+L = native.lib()
+L.rt_debug_wave_timing.argtypes = [C.c_void_p, C.c_size_t]
+names = ['cycles', 'rounds', 'nodefetch', 'boxtest', 'pop', 'leafrounds', 'leafload', 'leafmath', 'lanes_sum', 'service']
+for level in (0, 1, 2, 5, 9):
+    os.environ['RT_DEBUG_STOP_LEVEL'] = str(level)
+    dev.render(max_depth=10)
+    tm = np.zeros((8192, 10), dtype=np.uint64)
+    L.rt_debug_wave_timing(tm.ctypes.data, tm.size)
+    tm = tm[tm[:, 1] > 0].astype(np.float64)
+    tot = tm[:, 0].sum()
+    print('level', level, 'waves', len(tm), 'cycles mean %.0f max %.0f rounds mean %.1f max %.0f lanes/round %.1f' % (tm[:, 0].mean(), tm[:, 0].max(), tm[:, 1].mean(), tm[:, 1].max(), tm[:, 8].sum() / tm[:, 1].sum()))
+    print('   share of wave time: ' + ' '.join('%s %.1f%%' % (names[k], 100 * tm[:, k].sum() / tot) for k in (9, 4, 2, 3, 6, 7)),
+          '| per round: ' + ' '.join('%s %.0f' % (names[k], tm[:, k].sum() / tm[:, 1].sum()) for k in (9, 4, 2, 3, 6, 7)), 'leaf rounds %.0f%%' % (100 * tm[:, 5].sum() / tm[:, 1].sum()))
