@@ -31,10 +31,12 @@ WORKLOADS = {
 }
 
 # Algorithmic work of the reference's un-pruned traversal (what intersect.rs would execute), per
-# unit of the metric (one ray = one Scene::intersect call):
+# unit of the metric (one ray = one Scene::intersect call), counted by the oracle:
 #   bytes = 32*aabb_tests + 36*mesh_triangle_tests + 48*mesh_hits + 256*instance_transforms + 3*W*H
 #   flops = 27*aabb_tests + 57*(mesh_triangle_tests + triangle_tests) + 40*sphere_tests + 14*plane_tests
 #           + 90*instance_transforms + 60*light_shades
+# The BVH walk kernel (rt_traverse) owns the aabb_tests and mesh_triangle_tests terms; the instance
+# transforms and analytic primitives belong to rt_setup, normals and light sums to rt_shade / rt_phong.
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E
 FP32_NO_FMA_PEAK_TFLOPS = 78.6   # 157.3 TFLOP/s vector FP32 counts an FMA as two; contraction is forbidden here
 
@@ -42,11 +44,12 @@ FP32_NO_FMA_PEAK_TFLOPS = 78.6   # 157.3 TFLOP/s vector FP32 counts an FMA as tw
 def algorithmic_work(counters, width, height):
     from rust_raytracer_amd import abi
     c = {n: int(v) for n, v in zip(abi.COUNTER_NAMES, counters)}
-    nbytes = (32 * c["aabb_tests"] + 36 * c["mesh_triangle_tests"] + 48 * c["mesh_hits"]
-              + 256 * c["instance_transforms"] + 3 * width * height)
-    flops = (27 * c["aabb_tests"] + 57 * (c["mesh_triangle_tests"] + c["triangle_tests"]) + 40 * c["sphere_tests"]
-             + 14 * c["plane_tests"] + 90 * c["instance_transforms"] + 60 * c["light_shades"])
-    return nbytes, flops, c
+    walk_bytes = 32 * c["aabb_tests"] + 36 * c["mesh_triangle_tests"]
+    walk_flops = 27 * c["aabb_tests"] + 57 * c["mesh_triangle_tests"]
+    nbytes = walk_bytes + 48 * c["mesh_hits"] + 256 * c["instance_transforms"] + 3 * width * height
+    flops = (walk_flops + 57 * c["triangle_tests"] + 40 * c["sphere_tests"] + 14 * c["plane_tests"]
+             + 90 * c["instance_transforms"] + 60 * c["light_shades"])
+    return {"bytes": nbytes, "flops": flops, "walk_bytes": walk_bytes, "walk_flops": walk_flops}
 
 
 def cpu_baseline(scene_path, model_dir, width, height, max_depth, budget_s=12.0):
@@ -144,10 +147,22 @@ def main():
         # synchronise (the elapsed times are collected after the timed region)
     barrier()
     elapsed = time.perf_counter() - t0
-    # kernel time of the last frame's trace launches, from the library's HIP events
     trace_ms = dev.last_trace_ms()
     frame_ms = dev.last_render_ms()
     counts = dev.last_ray_counts().astype(np.int64)
+
+    # Per-kernel durations, live: the same steps once more with every launch of the four per-depth
+    # kernels bracketed by HIP events on the launch stream (outside the timed region above, so that
+    # the event records do not touch `value`).
+    kernel_ms = {k: [0.0, 0] for k in dev.LEVEL_KERNELS}
+    dev.set_kernel_timing(True)
+    for _ in range(args.steps):
+        sf.step()
+        for k, (ms, n) in dev.last_kernel_ms().items():        # waits for this frame's last event
+            kernel_ms[k][0] += ms
+            kernel_ms[k][1] += n
+    dev.set_kernel_timing(False)
+    barrier()
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     rays = torch.tensor(counts[:5], dtype=torch.int64, device="cuda")
@@ -181,18 +196,31 @@ def main():
             out["cpu_baseline"] = baseline
             # the frame the GPU produced must agree with the oracle's ray statistics
             assert [int(x) for x in ref_counters[:5]] == [int(x) for x in rays[:5]], "ray counts differ from the oracle"
+        # the dominant kernel is the BVH walk; its average launch duration comes from the events above
+        walk_ms, walk_launches = kernel_ms["rt_traverse"]
+        per_frame_launches = walk_launches // args.steps if args.steps else 0
+        avg_launch_ms = walk_ms / walk_launches if walk_launches else None
         roofline = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                    "kernel": "rt_trace_level", "launches_per_frame": max_depth,
-                    "avg_launch_ms": trace_ms / max_depth, "frame_kernel_ms": frame_ms}
-        if ref_counters is not None:
-            nbytes, flops, c = algorithmic_work(ref_counters, w, h)
-            per_launch = nbytes / max_depth
-            roofline["achieved"] = per_launch / (trace_ms / max_depth * 1e-3) / 1e9
+                    "kernel": "rt_traverse", "launches_per_frame": per_frame_launches, "avg_launch_ms": avg_launch_ms,
+                    "kernels_ms_per_frame": {k: (v[0] / args.steps if args.steps else None) for k, v in kernel_ms.items()},
+                    "trace_ms_per_frame": trace_ms, "frame_kernel_ms": frame_ms}
+        if ref_counters is not None and walk_launches:
+            work = algorithmic_work(ref_counters, w, h)
+            # per launch: the walk's share of the per-ray figure x the rays one launch handles (a frame's rays
+            # spread over its launches)
+            roofline["achieved"] = work["walk_bytes"] / per_frame_launches / (avg_launch_ms * 1e-3) / 1e9
             roofline["frac"] = roofline["achieved"] / HBM_PEAK_GBS
-            roofline["algorithmic_bytes_per_ray"] = nbytes / rays_per_frame
-            roofline["algorithmic_flops_per_ray"] = flops / rays_per_frame
-            roofline["valu"] = {"achieved": flops / (trace_ms * 1e-3) / 1e12, "peak": FP32_NO_FMA_PEAK_TFLOPS,
-                                "unit": "TFLOP/s", "frac": flops / (trace_ms * 1e-3) / 1e12 / FP32_NO_FMA_PEAK_TFLOPS}
+            roofline["algorithmic_bytes_per_ray"] = work["walk_bytes"] / rays_per_frame
+            roofline["algorithmic_flops_per_ray"] = work["walk_flops"] / rays_per_frame
+            roofline["rays_per_launch"] = rays_per_frame / per_frame_launches
+            walk_tflops = work["walk_flops"] / per_frame_launches / (avg_launch_ms * 1e-3) / 1e12
+            roofline["valu"] = {"achieved": walk_tflops, "peak": FP32_NO_FMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": walk_tflops / FP32_NO_FMA_PEAK_TFLOPS}
+            # all kernels of the recursion depths against the whole per-ray figure
+            roofline["whole_trace"] = {"algorithmic_bytes_per_ray": work["bytes"] / rays_per_frame,
+                                       "algorithmic_flops_per_ray": work["flops"] / rays_per_frame,
+                                       "achieved_GBs": work["bytes"] / (trace_ms * 1e-3) / 1e9,
+                                       "achieved_TFLOPs": work["flops"] / (trace_ms * 1e-3) / 1e12}
         traffic_file = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
         if os.path.exists(traffic_file):
             roofline["traffic"] = json.load(open(traffic_file)).get("hbm_bytes_per_launch")

@@ -247,9 +247,22 @@ int rt_last_ray_counts(RtScene* scene, uint64_t counters[RT_N_COUNTERS]);
  * enqueued command, measured with HIP events on the stream the kernels ran on. */
 int rt_last_render_ms(RtScene* scene, float* out_ms);
 
-/* The part of rt_last_render_ms spent in the per-depth trace launches (max_depth launches of the
- * one kernel that does all intersection and shading work), measured the same way. */
+/* The part of rt_last_render_ms spent in the launches of the recursion depths (everything between the
+ * primary-ray kernel and the resolve kernel), measured the same way. */
 int rt_last_trace_ms(RtScene* scene, float* out_ms);
+
+/* The four kernels launched per recursion depth: instance / analytic set-up, BVH walk, shading of the
+ * closest hits (raytracer.rs:65-135), Phong sum once the shadow rays are known (raytracer.rs:137-187). */
+enum { RT_KERNEL_SETUP = 0, RT_KERNEL_TRAVERSE, RT_KERNEL_SHADE, RT_KERNEL_PHONG, RT_N_LEVEL_KERNELS };
+
+/* Kernel timing mode (off by default): every launch of the four per-depth kernels is bracketed by HIP
+ * events on the launch stream.  No counterpart in the reference (its only timing is native_app's
+ * "Rendering took", main.rs:38-40); exists so that a benchmark can report the duration of one kernel. */
+int rt_set_kernel_timing(RtScene* scene, int enable);
+
+/* Summed duration (ms) and number of launches of each per-depth kernel in the last frame rendered in
+ * kernel timing mode. */
+int rt_last_kernel_ms(RtScene* scene, float out_ms[RT_N_LEVEL_KERNELS], uint32_t out_launches[RT_N_LEVEL_KERNELS]);
 
 void rt_scene_destroy(RtScene* scene);
 

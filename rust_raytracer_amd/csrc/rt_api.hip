@@ -16,7 +16,7 @@
 extern "C" {
 hipError_t rt_launch_generate(const DFrame* F, uint32_t blocks, hipStream_t stream);
 hipError_t rt_launch_level(const DScene* S, const DFrame* F, uint32_t level, uint32_t blocks, uint32_t traverse_blocks,
-                           hipStream_t stream);
+                           hipStream_t stream, hipEvent_t* marks);
 hipError_t rt_launch_resolve(const DFrame* F, uint8_t* out, uint32_t bytes_per_pixel, uint32_t tiled, hipStream_t stream);
 hipError_t rt_launch_resolve_aux(const DFrame* F, uint32_t* prim, uint32_t* inst, uint8_t* flags, hipStream_t stream);
 hipError_t rt_launch_assemble(const uint8_t* gathered, uint8_t* frame, uint32_t width, uint32_t height, uint32_t tiles_x,
@@ -69,6 +69,10 @@ struct RtScene {
     size_t aux_out_pixels = 0;
     uint32_t debug_queue_capacity = 0;
     size_t stats_words = 0;
+    // kernel timing mode (rt_set_kernel_timing): five events per recursion depth
+    bool kernel_timing = false;
+    std::vector<hipEvent_t> marks;
+    uint32_t marked_levels = 0;         // depths of the last frame that carry marks
 };
 
 template <class T>
@@ -335,6 +339,7 @@ extern "C" void rt_scene_destroy(RtScene* s) {
     if (s->d_aux_inst_out) (void)hipFree(s->d_aux_inst_out);
     if (s->d_aux_flags_out) (void)hipFree(s->d_aux_flags_out);
     if (s->h_overflow) (void)hipHostFree(s->h_overflow);
+    for (hipEvent_t e : s->marks) (void)hipEventDestroy(e);
     if (s->ev_start) (void)hipEventDestroy(s->ev_start);
     if (s->ev_stop) (void)hipEventDestroy(s->ev_stop);
     if (s->ev_trace_start) (void)hipEventDestroy(s->ev_trace_start);
@@ -467,8 +472,18 @@ static int enqueue_frame(RtScene* s, const RtRenderParams* p, bool sharded, bool
     HIP_TRY(hipEventRecord(s->ev_trace_start, stream));
     HIP_TRY(rt_launch_generate(&f, s->list_blocks, stream));
     const uint32_t last = s->d.n_lights > 0 ? max_depth : max_depth - 1;
+    s->marked_levels = 0;
+    if (s->kernel_timing) {
+        while (s->marks.size() < 5 * (size_t)(last + 1)) {
+            hipEvent_t e = nullptr;
+            HIP_TRY(hipEventCreate(&e));
+            s->marks.push_back(e);
+        }
+        s->marked_levels = last + 1;
+    }
     for (uint32_t level = 0; level <= last; ++level)
-        HIP_TRY(rt_launch_level(&s->d, &f, level, s->list_blocks, s->traverse_blocks, stream));
+        HIP_TRY(rt_launch_level(&s->d, &f, level, s->list_blocks, s->traverse_blocks, stream,
+                                s->kernel_timing ? &s->marks[5 * (size_t)level] : nullptr));
     HIP_TRY(hipEventRecord(s->ev_trace_stop, stream));
     HIP_TRY(rt_launch_resolve(&f, d_out, bytes_per_pixel(p->output_format), g.shard_count > 1 ? 1u : 0u, stream));
     HIP_TRY(hipEventRecord(s->ev_stop, stream));
@@ -597,6 +612,34 @@ extern "C" int rt_last_trace_ms(RtScene* s, float* out_ms) {
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipEventSynchronize(s->ev_trace_stop));
     HIP_TRY(hipEventElapsedTime(out_ms, s->ev_trace_start, s->ev_trace_stop));
+    return RT_OK;
+}
+
+extern "C" int rt_set_kernel_timing(RtScene* s, int enable) {
+    if (!s) return fail(RT_ERR_INVALID_ARGUMENT, "rt_set_kernel_timing: null argument");
+    s->kernel_timing = enable != 0;
+    return RT_OK;
+}
+
+extern "C" int rt_last_kernel_ms(RtScene* s, float out_ms[RT_N_LEVEL_KERNELS], uint32_t out_launches[RT_N_LEVEL_KERNELS]) {
+    if (!s || !out_ms || !out_launches) return fail(RT_ERR_INVALID_ARGUMENT, "rt_last_kernel_ms: null argument");
+    if (!s->timed || s->marked_levels == 0)
+        return fail(RT_ERR_INVALID_ARGUMENT, "the last frame was not rendered in kernel timing mode (rt_set_kernel_timing)");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipEventSynchronize(s->ev_stop));
+    for (int k = 0; k < RT_N_LEVEL_KERNELS; ++k) { out_ms[k] = 0.0f; out_launches[k] = 0; }
+    for (uint32_t level = 0; level < s->marked_levels; ++level) {
+        const hipEvent_t* m = &s->marks[5 * (size_t)level];
+        for (int k = 0; k < RT_N_LEVEL_KERNELS; ++k) {
+            const bool launched = k == RT_KERNEL_SETUP || k == RT_KERNEL_SHADE || (k == RT_KERNEL_TRAVERSE && s->d.n_instances > 0) ||
+                                  (k == RT_KERNEL_PHONG && level > 0 && s->d.n_lights > 0);
+            if (!launched) continue;
+            float ms = 0.0f;
+            HIP_TRY(hipEventElapsedTime(&ms, m[k], m[k + 1]));
+            out_ms[k] += ms;
+            out_launches[k] += 1;
+        }
+    }
     return RT_OK;
 }
 

@@ -496,6 +496,19 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_generate(const DFrame F) 
     if (threadIdx.x == 0) F.ray_counts[0][blockIdx.x] = out_n < F.seg_rays ? out_n : F.seg_rays;
 }
 
+#ifdef RT_STATS
+// Diagnostic build: per wave of the last rt_traverse launch: cycles, rounds, refill cycles, refills, cycles and
+// count of rounds in which some lane tested a leaf, cycles and count of the other rounds, sum of walking lanes.
+__device__ unsigned long long g_wave_timing[8192 * 10];
+__device__ unsigned long long g_setup_timing[8192 * 8];
+extern "C" hipError_t rt_debug_wave_timing(unsigned long long* out, size_t n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_timing), n * sizeof(unsigned long long));
+}
+extern "C" hipError_t rt_debug_setup_timing(unsigned long long* out, size_t n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_setup_timing), n * sizeof(unsigned long long));
+}
+#endif
+
 // ======================================================================================================
 // Kernel A: per ray, the analytic primitives (scene.rs:129-131) and the root test of every mesh instance.
 // Writes the best analytic candidate to F.best and one BVH work item per instance whose root box the ray
@@ -509,7 +522,14 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_setup(const DScene S, con
     __shared__ uint32_t out_n;
     if (threadIdx.x == 0) out_n = 0;
     const uint32_t p = level & 1;
+#ifdef RT_STATS
+    unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long ts_begin = clock64();
+#endif
     const uint32_t n_rays = build_prefix(F.ray_counts[p], F.n_seg, F.seg_rays, F.ovf_rays, pre, scratch);
+#ifdef RT_STATS
+    ts[1] = clock64() - ts_begin;
+#endif
     const float4* rays = F.rays[p];
     const uint32_t lane = threadIdx.x & (RT_WAVE - 1);
     const uint32_t gwave = (blockIdx.x * blockDim.x + threadIdx.x) / RT_WAVE;
@@ -523,9 +543,18 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_setup(const DScene S, con
         rr.ray.o = rr.ray.d = mk(0, 0, 0);
         rr.throughput = 0.0f;
         rr.meta = 0;
+#ifdef RT_STATS
+        const unsigned long long tc0 = clock64();
+        ts[2] += 1;
+#endif
         if (active) { gi = locate(pre, F.n_seg, F.seg_rays, v); rr = load_rec(rays, gi); }
         const Ray r = rr.ray;
         const ShadowSpec ss = shadow_spec(S, rr);
+#ifdef RT_STATS
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const unsigned long long tc1 = clock64();
+        ts[3] += tc1 - tc0;
+#endif
         const bool ray_finite = finite3(r.o) && finite3(r.d);
         const bool early = ss.is_shadow && (ss.directional || ray_finite);
 
@@ -565,6 +594,10 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_setup(const DScene S, con
             }
         }
 
+#ifdef RT_STATS
+        const unsigned long long tc2 = clock64();
+        ts[4] += tc2 - tc1;
+#endif
         // mesh instances in Vec order (scene.rs:133-136)
         const float o_l1 = fabsf(r.o.x) + fabsf(r.o.y) + fabsf(r.o.z);
         bool exact_mesh = false;             // exact path: the winner so far is a mesh triangle
@@ -611,6 +644,10 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_setup(const DScene S, con
             uint32_t slot = append_slot(want_item, &out_n, F.seg_items, F.n_seg, F.item_counts, F.ovf_items, F.overflow, lane);
             if (slot != RT_REF_NONE) F.items[slot] = make_uint2(gi, ii);
         }
+#ifdef RT_STATS
+        const unsigned long long tc3 = clock64();
+        ts[5] += tc3 - tc2;
+#endif
         // a mesh winner found on the exact path is recorded as a finished work item
         {
             uint32_t slot = append_slot(active && exact_mesh, &out_n, F.seg_items, F.n_seg, F.item_counts, F.ovf_items, F.overflow, lane);
@@ -630,7 +667,14 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_setup(const DScene S, con
                                                         : (((unsigned long long)__float_as_uint(best_t) << 32) | best_order);
             F.best[gi] = key;
         }
+#ifdef RT_STATS
+        ts[6] += clock64() - tc3;
+#endif
     }
+#ifdef RT_STATS
+    ts[0] = clock64() - ts_begin;
+    if (lane == 0 && gwave < 8192) for (int k = 0; k < 8; ++k) g_setup_timing[gwave * 8 + k] = ts[k];
+#endif
     __syncthreads();
     if (threadIdx.x == 0) F.item_counts[blockIdx.x] = out_n < F.seg_items ? out_n : F.seg_items;
 }
@@ -653,14 +697,6 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_setup(const DScene S, con
 // The per-lane stack lives in LDS: entry e of lane l is stack[e * 64 + l] (child reference) and
 // stack[(entries + e) * 64 + l] (box entry distance).
 // ======================================================================================================
-#ifdef RT_STATS
-// Diagnostic build: per wave of the last rt_traverse launch: cycles, rounds, refill cycles, refills, cycles and
-// count of rounds in which some lane tested a leaf, cycles and count of the other rounds, sum of walking lanes.
-__device__ unsigned long long g_wave_timing[8192 * 10];
-extern "C" hipError_t rt_debug_wave_timing(unsigned long long* out, size_t n) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_timing), n * sizeof(unsigned long long));
-}
-#endif
 
 __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, const DFrame F, const uint32_t level) {
     extern __shared__ uint32_t lds[];
@@ -1310,24 +1346,30 @@ extern "C" hipError_t rt_launch_generate(const DFrame* F, uint32_t blocks, hipSt
 
 // One recursion depth: A, B, C and (from depth 1 on) D.  `blocks` is the grid of the list-producing
 // kernels (F->n_seg - 1), `traverse_blocks` that of the BVH walk.
+// `marks`, when not null, are five events recorded before A and after A, B, C and D (kernel timing mode).
 extern "C" hipError_t rt_launch_level(const DScene* S, const DFrame* F, uint32_t level, uint32_t blocks,
-                                      uint32_t traverse_blocks, hipStream_t stream) {
+                                      uint32_t traverse_blocks, hipStream_t stream, hipEvent_t* marks) {
     const size_t lds = list_lds_bytes(F->n_seg);
 #ifdef RT_STATS
     const char* stop = getenv("RT_DEBUG_STOP_LEVEL");           // keep the lists of that depth as rt_traverse left them
     if (stop && level > (uint32_t)atoi(stop)) return hipSuccess;
 #endif
     hipLaunchKernelGGL(rt_level_reset, dim3(1), dim3(1), 0, stream, *F, level);
+    if (marks) (void)hipEventRecord(marks[0], stream);
     hipLaunchKernelGGL(rt_setup, dim3(blocks), dim3(RT_BLOCK_THREADS), lds, stream, *S, *F, level);
+    if (marks) (void)hipEventRecord(marks[1], stream);
     if (S->n_instances > 0)
         hipLaunchKernelGGL(rt_traverse, dim3(traverse_blocks), dim3(RT_BLOCK_THREADS), traverse_lds_bytes(F->n_seg, S->stack_entries),
                            stream, *S, *F, level);
 #ifdef RT_STATS
     if (stop && level == (uint32_t)atoi(stop)) return hipGetLastError();
 #endif
+    if (marks) (void)hipEventRecord(marks[2], stream);
     hipLaunchKernelGGL(rt_shade, dim3(blocks), dim3(RT_BLOCK_THREADS), lds, stream, *S, *F, level);
+    if (marks) (void)hipEventRecord(marks[3], stream);
     if (level > 0 && S->n_lights > 0)
         hipLaunchKernelGGL(rt_phong, dim3(blocks), dim3(RT_BLOCK_THREADS), lds, stream, *S, *F, level);
+    if (marks) (void)hipEventRecord(marks[4], stream);
     return hipGetLastError();
 }
 

@@ -14,7 +14,8 @@ LIB_PATH = os.path.join(_HERE, "librt_hip.so")
 
 # every function include/rt_hip.h declares
 EXPORTS = ["rt_scene_create", "rt_scene_set_camera", "rt_render", "rt_render_device", "rt_shard_bytes",
-           "rt_assemble_shards", "rt_last_ray_counts", "rt_last_render_ms", "rt_last_trace_ms", "rt_scene_destroy",
+           "rt_assemble_shards", "rt_last_ray_counts", "rt_last_render_ms", "rt_last_trace_ms", "rt_set_kernel_timing",
+           "rt_last_kernel_ms", "rt_scene_destroy",
            "rt_debug_set_queue_capacity", "rt_debug_last_spilled", "rt_last_error"]
 # every function include/rt_host.h declares
 HOST_EXPORTS = ["rt_host_scene_parse", "rt_host_scene_load", "rt_host_scene_desc", "rt_host_scene_camera",
@@ -53,6 +54,8 @@ def lib():
         L.rt_last_ray_counts.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.rt_last_render_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.rt_last_trace_ms.argtypes = [vp, C.POINTER(C.c_float)]
+        L.rt_set_kernel_timing.argtypes = [vp, C.c_int]
+        L.rt_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
         L.rt_scene_destroy.argtypes = [vp]
         L.rt_scene_destroy.restype = None
         L.rt_debug_set_queue_capacity.argtypes = [vp, u32]
@@ -160,6 +163,18 @@ class DeviceScene:
         ms = C.c_float()
         check(lib().rt_last_trace_ms(self._h, C.byref(ms)))
         return float(ms.value)
+
+    LEVEL_KERNELS = ("rt_setup", "rt_traverse", "rt_shade", "rt_phong")
+
+    def set_kernel_timing(self, enable: bool):
+        check(lib().rt_set_kernel_timing(self._h, 1 if enable else 0))
+
+    def last_kernel_ms(self) -> dict:
+        """{kernel name: (summed ms, launches)} of the last frame rendered in kernel timing mode."""
+        ms = (C.c_float * 4)()
+        n = (C.c_uint32 * 4)()
+        check(lib().rt_last_kernel_ms(self._h, ms, n))
+        return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(self.LEVEL_KERNELS)}
 
     def debug_set_queue_capacity(self, capacity: int):
         check(lib().rt_debug_set_queue_capacity(self._h, capacity))
