@@ -251,11 +251,13 @@ int rt_last_render_ms(RtScene* scene, float* out_ms);
  * primary-ray kernel and the resolve kernel), measured the same way. */
 int rt_last_trace_ms(RtScene* scene, float* out_ms);
 
-/* The four kernels launched per recursion depth: instance / analytic set-up, BVH walk, shading of the
- * closest hits (raytracer.rs:65-135), Phong sum once the shadow rays are known (raytracer.rs:137-187). */
-enum { RT_KERNEL_SETUP = 0, RT_KERNEL_TRAVERSE, RT_KERNEL_SHADE, RT_KERNEL_PHONG, RT_N_LEVEL_KERNELS };
+/* The kernels launched per recursion depth: analytic primitives and instance culling, local rays and root
+ * boxes of the surviving (ray, instance) pairs (intersect.rs:296-308), BVH walk (intersect.rs:228-269),
+ * shading of the closest hits (raytracer.rs:65-135), Phong sum once the shadow rays are known
+ * (raytracer.rs:137-187). */
+enum { RT_KERNEL_SETUP = 0, RT_KERNEL_ROOT, RT_KERNEL_TRAVERSE, RT_KERNEL_SHADE, RT_KERNEL_PHONG, RT_N_LEVEL_KERNELS };
 
-/* Kernel timing mode (off by default): every launch of the four per-depth kernels is bracketed by HIP
+/* Kernel timing mode (off by default): every launch of the per-depth kernels is bracketed by HIP
  * events on the launch stream.  No counterpart in the reference (its only timing is native_app's
  * "Rendering took", main.rs:38-40); exists so that a benchmark can report the duration of one kernel. */
 int rt_set_kernel_timing(RtScene* scene, int enable);

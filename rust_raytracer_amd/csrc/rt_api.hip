@@ -3,6 +3,7 @@
 // run, every entry point fails with RT_ERR_DEVICE / RT_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -69,7 +70,7 @@ struct RtScene {
     size_t aux_out_pixels = 0;
     uint32_t debug_queue_capacity = 0;
     size_t stats_words = 0;
-    // kernel timing mode (rt_set_kernel_timing): five events per recursion depth
+    // kernel timing mode (rt_set_kernel_timing): six events per recursion depth
     bool kernel_timing = false;
     std::vector<hipEvent_t> marks;
     uint32_t marked_levels = 0;         // depths of the last frame that carry marks
@@ -194,6 +195,60 @@ static int layout_mesh(const RtSceneDesc* desc, uint32_t mesh_index, std::vector
     return RT_OK;
 }
 
+// World-space culling box of an instance, see DInstance.  Every hit the reference can report on the instance
+// lies, in mesh-local space, inside the root box (up to float rounding), and its world position is
+// model * (that point +- 1e-4 * unit normal) (intersect.rs:312-316, 379-385).  The box is the model transform
+// of the root box's corners, padded by far more than those effects: 1/128 of its extent, 1/4096 of its
+// largest coordinate and twice the normal offset.  It is only trusted when the four matrices are finite,
+// moderate in size and consistent with each other (model_inverse * model = I to 1e-5), and only for rays
+// whose origin is within 4096 extents, so that the rounding of the reference's own local ray
+// (relative 2^-23 of the origin's size) stays below the padding as well.
+static void instance_world_box(const RtMeshInstance& in, const MeshLayout& ml, double fro_rs, DInstance* o) {
+    o->cullable = 0;
+    o->cull_origin_limit = 0.0f;
+    for (int c = 0; c < 3; ++c) { o->world_lo[c] = 0.0f; o->world_hi[c] = 0.0f; }
+    const float* mats[4] = {in.model, in.model_inverse, in.rotation_scale, in.rotation_scale_inverse};
+    for (const float* m : mats)
+        for (int k = 0; k < 16; ++k)
+            if (!(std::fabs((double)m[k]) <= 1e15)) return;                       // also catches NaN
+    auto consistent = [](const float* a, const float* b) {
+        for (int r = 0; r < 4; ++r)
+            for (int c = 0; c < 4; ++c) {
+                double v = 0.0;
+                for (int k = 0; k < 4; ++k) v += (double)a[4 * k + r] * (double)b[4 * c + k];
+                if (!(std::fabs(v - (r == c ? 1.0 : 0.0)) <= 1e-5)) return false;
+            }
+        return true;
+    };
+    if (!consistent(in.model_inverse, in.model) || !consistent(in.rotation_scale_inverse, in.rotation_scale)) return;
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int corner = 0; corner < 8; ++corner) {
+        double p[3];
+        for (int c = 0; c < 3; ++c) p[c] = (corner >> c & 1) ? (double)ml.root_hi[c] : (double)ml.root_lo[c];
+        if (!(std::fabs(p[0]) <= 1e15 && std::fabs(p[1]) <= 1e15 && std::fabs(p[2]) <= 1e15)) return;
+        for (int r = 0; r < 3; ++r) {
+            double w = (double)in.model[12 + r];
+            for (int c = 0; c < 3; ++c) w += (double)in.model[4 * c + r] * p[c];
+            if (w < lo[r]) lo[r] = w;
+            if (w > hi[r]) hi[r] = w;
+        }
+    }
+    double ext = 0.0, mag = 0.0;
+    for (int c = 0; c < 3; ++c) {
+        if (!(lo[c] <= hi[c])) return;
+        ext = std::max(ext, hi[c] - lo[c]);
+        mag = std::max(mag, std::max(std::fabs(lo[c]), std::fabs(hi[c])));
+    }
+    if (!(ext > 0.0) || !(mag <= 1e15)) return;
+    const double pad = ext / 128.0 + mag / 4096.0 + 2e-4 * fro_rs;
+    for (int c = 0; c < 3; ++c) {
+        o->world_lo[c] = std::nextafter((float)(lo[c] - pad), -INFINITY);
+        o->world_hi[c] = std::nextafter((float)(hi[c] + pad), INFINITY);
+    }
+    o->cull_origin_limit = (float)(4096.0 * ext);
+    o->cullable = 1;
+}
+
 extern "C" int rt_scene_create(const RtSceneDesc* desc, int device_id, RtScene** out_scene) {
     if (!desc || !out_scene) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: null argument");
     *out_scene = nullptr;
@@ -285,6 +340,7 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device_id, RtScene**
             for (int r = 0; r < 3; ++r) fro += (double)in.rotation_scale[4 * c + r] * in.rotation_scale[4 * c + r];
         o.world_guard = (float)(1.5e-4 * std::sqrt(fro));
         if (!(o.world_guard == o.world_guard) || o.world_guard > 1e30f) o.prunable = 0;
+        instance_world_box(in, ml, std::sqrt(fro), &o);
         if (ml.stack_need > stack_entries) stack_entries = ml.stack_need;
     }
     if (stack_entries > RT_BVH_STACK_LEN)
@@ -308,6 +364,11 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device_id, RtScene**
     s->d.n_lights = desc->n_lights; s->d.n_planes = desc->n_planes; s->d.n_spheres = desc->n_spheres;
     s->d.n_triangles = desc->n_triangles; s->d.n_instances = desc->n_mesh_instances;
     s->d.stack_entries = stack_entries;
+    s->d.all_cullable = 1;
+    for (const DInstance& di : instances) {
+        if (di.root_ref == RT_REF_NONE) continue;                  // an empty mesh is never tested
+        if (!di.cullable) s->d.all_cullable = 0;
+    }
     if ((rc = upload(s, lights, &s->d.lights)) || (rc = upload(s, materials, &s->d.materials)) ||
         (rc = upload(s, planes, &s->d.planes)) || (rc = upload(s, spheres, &s->d.spheres)) ||
         (rc = upload(s, triangles, &s->d.triangles)) || (rc = upload(s, instances, &s->d.instances)) ||
@@ -410,10 +471,12 @@ static int ensure_frame(RtScene* s, const Geometry& g, uint32_t max_depth, bool 
         memset(&f, 0, sizeof(f));
         f.n_seg = blocks + 1;
         f.seg_rays = ceil_div(capacity, blocks);          f.ovf_rays = (uint32_t)(capacity / 4 + 1024);
-        f.seg_items = ceil_div(capacity / 2, blocks);     f.ovf_items = (uint32_t)(capacity / 8 + 1024);
+        f.seg_items = ceil_div(capacity, blocks);         f.ovf_items = (uint32_t)(capacity / 4 + 1024);
+        f.seg_fat = ceil_div(capacity / 2, blocks);       f.ovf_fat = (uint32_t)(capacity / 8 + 1024);
         f.seg_hits = ceil_div(capacity / 2, blocks);      f.ovf_hits = (uint32_t)(capacity / 8 + 1024);
         const size_t ray_slots = (size_t)blocks * f.seg_rays + f.ovf_rays;
         const size_t item_slots = (size_t)blocks * f.seg_items + f.ovf_items;
+        const size_t fat_slots = (size_t)blocks * f.seg_fat + f.ovf_fat;
         const size_t hit_slots = (size_t)blocks * f.seg_hits + f.ovf_hits;
         const size_t flag_bytes = hit_slots * (s->d.n_lights ? s->d.n_lights : 1);
         s->stats_words = (size_t)blocks * 4 * 8;
@@ -423,7 +486,9 @@ static int ensure_frame(RtScene* s, const Geometry& g, uint32_t max_depth, bool 
             (rc = frame_alloc(s, f.n_seg, &f.ray_counts[0])) || (rc = frame_alloc(s, f.n_seg, &f.ray_counts[1])) ||
             (rc = frame_alloc(s, ray_slots, &f.best)) ||
             (rc = frame_alloc(s, item_slots, &f.items)) || (rc = frame_alloc(s, item_slots, &f.item_results)) ||
-            (rc = frame_alloc(s, f.n_seg, &f.item_counts)) || (rc = frame_alloc(s, RT_MAX_DEPTH_LIMIT + 2, &f.chunk_counter)) ||
+            (rc = frame_alloc(s, f.n_seg, &f.item_counts)) || (rc = frame_alloc(s, 4 * fat_slots, &f.fat_items)) ||
+            (rc = frame_alloc(s, f.n_seg, &f.fat_counts)) || (rc = frame_alloc(s, ray_slots, &f.slow_rays)) ||
+            (rc = frame_alloc(s, f.n_seg, &f.slow_counts)) || (rc = frame_alloc(s, RT_MAX_DEPTH_LIMIT + 2, &f.slow_flags)) || (rc = frame_alloc(s, RT_MAX_DEPTH_LIMIT + 2, &f.chunk_counter)) ||
             (rc = frame_alloc(s, 3 * hit_slots, &f.hits[0])) || (rc = frame_alloc(s, 3 * hit_slots, &f.hits[1])) ||
             (rc = frame_alloc(s, f.n_seg, &f.hit_counts[0])) || (rc = frame_alloc(s, f.n_seg, &f.hit_counts[1])) ||
             (rc = frame_alloc(s, flag_bytes, &f.shadow_flags[0])) || (rc = frame_alloc(s, flag_bytes, &f.shadow_flags[1])) ||
@@ -468,13 +533,14 @@ static int enqueue_frame(RtScene* s, const RtRenderParams* p, bool sharded, bool
     HIP_TRY(hipMemsetAsync(f.wave_stats, 0, s->stats_words * sizeof(unsigned int), stream));
     HIP_TRY(hipMemsetAsync(f.ray_counts[0], 0, f.n_seg * sizeof(unsigned int), stream));
     HIP_TRY(hipMemsetAsync(f.chunk_counter, 0, (RT_MAX_DEPTH_LIMIT + 2) * sizeof(unsigned int), stream));
+    HIP_TRY(hipMemsetAsync(f.slow_flags, 0, (RT_MAX_DEPTH_LIMIT + 2) * sizeof(unsigned int), stream));
     if (aux) HIP_TRY(hipMemsetAsync(f.aux_flags, 0, (size_t)g.n_pixels * sizeof(unsigned int), stream));
     HIP_TRY(hipEventRecord(s->ev_trace_start, stream));
     HIP_TRY(rt_launch_generate(&f, s->list_blocks, stream));
     const uint32_t last = s->d.n_lights > 0 ? max_depth : max_depth - 1;
     s->marked_levels = 0;
     if (s->kernel_timing) {
-        while (s->marks.size() < 5 * (size_t)(last + 1)) {
+        while (s->marks.size() < (RT_N_LEVEL_KERNELS + 1) * (size_t)(last + 1)) {
             hipEvent_t e = nullptr;
             HIP_TRY(hipEventCreate(&e));
             s->marks.push_back(e);
@@ -483,7 +549,7 @@ static int enqueue_frame(RtScene* s, const RtRenderParams* p, bool sharded, bool
     }
     for (uint32_t level = 0; level <= last; ++level)
         HIP_TRY(rt_launch_level(&s->d, &f, level, s->list_blocks, s->traverse_blocks, stream,
-                                s->kernel_timing ? &s->marks[5 * (size_t)level] : nullptr));
+                                s->kernel_timing ? &s->marks[(RT_N_LEVEL_KERNELS + 1) * (size_t)level] : nullptr));
     HIP_TRY(hipEventRecord(s->ev_trace_stop, stream));
     HIP_TRY(rt_launch_resolve(&f, d_out, bytes_per_pixel(p->output_format), g.shard_count > 1 ? 1u : 0u, stream));
     HIP_TRY(hipEventRecord(s->ev_stop, stream));
@@ -629,9 +695,10 @@ extern "C" int rt_last_kernel_ms(RtScene* s, float out_ms[RT_N_LEVEL_KERNELS], u
     HIP_TRY(hipEventSynchronize(s->ev_stop));
     for (int k = 0; k < RT_N_LEVEL_KERNELS; ++k) { out_ms[k] = 0.0f; out_launches[k] = 0; }
     for (uint32_t level = 0; level < s->marked_levels; ++level) {
-        const hipEvent_t* m = &s->marks[5 * (size_t)level];
+        const hipEvent_t* m = &s->marks[(RT_N_LEVEL_KERNELS + 1) * (size_t)level];
         for (int k = 0; k < RT_N_LEVEL_KERNELS; ++k) {
-            const bool launched = k == RT_KERNEL_SETUP || k == RT_KERNEL_SHADE || (k == RT_KERNEL_TRAVERSE && s->d.n_instances > 0) ||
+            const bool launched = k == RT_KERNEL_SETUP || k == RT_KERNEL_SHADE ||
+                                  ((k == RT_KERNEL_TRAVERSE || k == RT_KERNEL_ROOT) && s->d.n_instances > 0) ||
                                   (k == RT_KERNEL_PHONG && level > 0 && s->d.n_lights > 0);
             if (!launched) continue;
             float ms = 0.0f;

@@ -56,7 +56,20 @@ struct DInstance {
     uint32_t prunable;              // 1: distance pruning and near-first ordering are provably result-preserving
     float prune_abs;                // absolute slack (mesh-local units) added to every pruning comparison
     float world_guard;              // bound on |t_world - k * t_local| for hits on this instance (world units)
+    // World-space box around everything a ray can hit on this instance (the model transform of the root box,
+    // padded).  A ray that misses it cannot hit the instance, so no local ray has to be derived for it.
+    uint32_t cullable;              // 0: the box is not trusted (degenerate or inconsistent matrices)
+    float cull_origin_limit;        // the box is only used for rays whose origin has a smaller L1 norm
+    float world_lo[3], world_hi[3];
 };
+
+// A BVH work item as the walk consumes it (64 B): the mesh-local ray and everything else it needs, so
+// that starting a walk is one fetch.
+//   q0 = (local origin, entry distance into the root box)     q1 = (local direction, local bound on useful t)
+//   q2 = (1 / |rotation_scale_inverse * d|, shadow threshold, prune_abs, bits root reference)
+//   q3 = (bits ray slot, bits instance | RT_FAT_FAST, bits work item index, 0)
+// shadow threshold: a candidate with local t * q2.x below it proves a shadow ray blocked (-inf for other rays).
+#define RT_FAT_FAST 0x80000000u
 
 // A child reference: inner node index, or a leaf given by its first triangle slot and its count.
 #define RT_REF_NONE 0xFFFFFFFFu
@@ -69,6 +82,7 @@ struct DScene {
     RtBackground background;
     uint32_t n_lights, n_planes, n_spheres, n_triangles, n_instances;
     uint32_t stack_entries;      // per-lane traversal stack entries any mesh can need (<= RT_BVH_STACK_LEN)
+    uint32_t all_cullable;       // every instance has a usable culling box (DInstance::cullable)
     const DLight* lights;
     const RtMaterial* materials;
     const DPlane* planes;
@@ -103,7 +117,8 @@ struct DFrame {
     uint32_t max_depth;
     uint32_t n_seg;                  // producer blocks + 1 (the last segment is the shared overflow segment)
     uint32_t seg_rays, ovf_rays;     // capacity of a block's ray segment / of the overflow segment
-    uint32_t seg_items, ovf_items;
+    uint32_t seg_items, ovf_items;   // (ray, instance) pairs that pass the culling box
+    uint32_t seg_fat, ovf_fat;       // pairs that pass the exact root-box test
     uint32_t seg_hits, ovf_hits;
     long long* acc;                  // [3][n_pixels] fixed-point colour sums, 2^-40 units
     unsigned int* poison;            // [n_pixels] non-finite contributions, see rt_kernels.hip
@@ -116,6 +131,11 @@ struct DFrame {
     uint2* items;                    // BVH work items: (ray slot, instance | flags)
     float4* item_results;            // per item: local t, u, v, bits triangle slot
     unsigned int* item_counts;       // [n_seg]
+    float4* fat_items;               // 4 float4 per entry, segmented like the other lists
+    unsigned int* fat_counts;        // [n_seg]
+    unsigned int* slow_rays;         // ray slots rt_setup left to rt_setup_slow, segmented like the ray lists
+    unsigned int* slow_counts;       // [n_seg]
+    unsigned int* slow_flags;        // [RT_MAX_DEPTH_LIMIT + 2] set when a depth has such rays
     unsigned int* chunk_counter;     // [RT_MAX_DEPTH_LIMIT + 2] input chunks of the BVH walk handed out so far, per depth
     float4* hits[2];                 // Phong-shaded hits waiting for their shadow rays, 3 float4 each
     unsigned int* hit_counts[2];     // [n_seg]

@@ -114,16 +114,16 @@ __device__ __forceinline__ bool plane_t(const DPlane& p, const Ray& r, float& t)
 }
 
 // intersect.rs:38-112
-__device__ __forceinline__ bool sphere_t(const DSphere& s, const Ray& r, float& t) {
+// `a` = dot(d, d) and `dn` = normalize(d) depend on the ray only; callers with several spheres compute them once
+// (same operands, same result as the reference's per-sphere evaluation).
+__device__ __forceinline__ bool sphere_t(const DSphere& s, const Ray& r, float a, V3 dn, float& t) {
     V3 c = ld3(s.c);
     float radius = s.r;
     V3 m = r.o - c;
-    float a = dot3(r.d, r.d);
     float b = 2.0f * dot3(m, r.d);
     float cc = dot3(m, m) - radius * radius;
-    V3 dn = normalize3(r.d);
     V3 proj = m - dn * dot3(m, dn);
-    float disc = 4.0f * dot3(r.d, r.d) * (radius * radius - dot3(proj, proj));
+    float disc = 4.0f * a * (radius * radius - dot3(proj, proj));
     if (disc == 0.0f) {
         t = (-0.5f * b) / a;
     } else if (!(__float_as_uint(disc) >> 31)) {          // Signed::is_positive = sign bit clear
@@ -468,6 +468,54 @@ __device__ __forceinline__ ShadowSpec shadow_spec(const DScene& S, const RayRec&
     return s;
 }
 
+// Scene::intersect's three analytic groups (scene.rs:129-131 over intersect.rs:20-36): per group the closest
+// hit in Vec order, groups merged with the strict `<` of utils/mod.rs:17.  `settled`: a shadow ray that is
+// already known to be blocked needs nothing further (raytracer.rs:171-187).
+__device__ __forceinline__ void analytic_hits(const DScene& S, const DPlane* planes, const DSphere* spheres,
+                                              const DTriangle* triangles, const Ray& r, bool early, const ShadowSpec& ss,
+                                              bool& have, float& best_t, uint32_t& best_order, bool& settled) {
+    {
+        bool g_have = false; float g_t = 0.0f; uint32_t g_i = 0;
+        for (uint32_t i = 0; i < S.n_planes; ++i) {
+            float t;
+            if (plane_t(planes[i], r, t) && closer(g_have, g_t, t)) { g_have = true; g_t = t; g_i = i; }
+        }
+        if (g_have && closer(have, best_t, g_t)) { have = true; best_t = g_t; best_order = analytic_order(RT_PRIM_PLANE, g_i); }
+    }
+    settled = early && have && (ss.directional || best_t < ss.limit_world);
+    if (!settled) {
+        bool g_have = false; float g_t = 0.0f; uint32_t g_i = 0;
+        const float dd = dot3(r.d, r.d);
+        const V3 dn = normalize3(r.d);
+        for (uint32_t i = 0; i < S.n_spheres; ++i) {
+            float t;
+            if (sphere_t(spheres[i], r, dd, dn, t) && closer(g_have, g_t, t)) { g_have = true; g_t = t; g_i = i; }
+        }
+        if (g_have && closer(have, best_t, g_t)) { have = true; best_t = g_t; best_order = analytic_order(RT_PRIM_SPHERE, g_i); }
+        settled = early && have && (ss.directional || best_t < ss.limit_world);
+    }
+    if (!settled) {
+        bool g_have = false; float g_t = 0.0f; uint32_t g_i = 0;
+        for (uint32_t i = 0; i < S.n_triangles; ++i) {
+            const DTriangle& tr = triangles[i];
+            float t, u, w;
+            if (triangle_tuv(ld3(tr.p0), ld3(tr.e1), ld3(tr.e2), r, t, u, w) && closer(g_have, g_t, t)) {
+                g_have = true; g_t = t; g_i = i;
+            }
+        }
+        if (g_have && closer(have, best_t, g_t)) { have = true; best_t = g_t; best_order = analytic_order(RT_PRIM_TRIANGLE, g_i); }
+        settled = early && have && (ss.directional || best_t < ss.limit_world);
+    }
+}
+
+// Words of LDS the analytic primitives take when staged (rt_setup), 0 when they are too many to stage.
+#define RT_STAGE_WORDS_MAX 4096
+__host__ __device__ inline uint32_t analytic_stage_words(const DScene& S) {
+    const unsigned long long w = (unsigned long long)S.n_planes * (sizeof(DPlane) / 4) + (unsigned long long)S.n_spheres * (sizeof(DSphere) / 4) +
+                                 (unsigned long long)S.n_triangles * (sizeof(DTriangle) / 4);
+    return w <= RT_STAGE_WORDS_MAX ? (uint32_t)w : 0u;
+}
+
 }  // namespace
 
 // ======================================================================================================
@@ -519,14 +567,33 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_setup(const DScene S, con
     extern __shared__ uint32_t lds[];
     uint32_t* pre = lds;                       // n_seg + 1
     uint32_t* scratch = lds + F.n_seg + 1;     // blockDim.x
-    __shared__ uint32_t out_n;
-    if (threadIdx.x == 0) out_n = 0;
+    __shared__ uint32_t out_n, slow_n;
+    if (threadIdx.x == 0) { out_n = 0; slow_n = 0; }
     const uint32_t p = level & 1;
 #ifdef RT_STATS
     unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long ts_begin = clock64();
 #endif
     const uint32_t n_rays = build_prefix(F.ray_counts[p], F.n_seg, F.seg_rays, F.ovf_rays, pre, scratch);
+    // the analytic primitives are staged in LDS (every lane reads the same one: a broadcast, no scalar-load
+    // round trip per primitive)
+    uint32_t* stage = lds + F.n_seg + 1 + blockDim.x;
+    const uint32_t stage_words = analytic_stage_words(S);
+    const bool staged = stage_words != 0;
+    const uint32_t plane_words = S.n_planes * (sizeof(DPlane) / 4), sphere_words = S.n_spheres * (sizeof(DSphere) / 4);
+    const DPlane* ld_planes = (const DPlane*)stage;
+    const DSphere* ld_spheres = (const DSphere*)(stage + plane_words);
+    const DTriangle* ld_triangles = (const DTriangle*)(stage + plane_words + sphere_words);
+    if (staged) {
+        for (uint32_t w = threadIdx.x; w < stage_words; w += blockDim.x) {
+            uint32_t v;
+            if (w < plane_words) v = ((const uint32_t*)S.planes)[w];
+            else if (w < plane_words + sphere_words) v = ((const uint32_t*)S.spheres)[w - plane_words];
+            else v = ((const uint32_t*)S.triangles)[w - plane_words - sphere_words];
+            stage[w] = v;
+        }
+        __syncthreads();
+    }
 #ifdef RT_STATS
     ts[1] = clock64() - ts_begin;
 #endif
@@ -537,7 +604,7 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_setup(const DScene S, con
 
     for (uint32_t c = gwave; (unsigned long long)c * RT_WAVE < n_rays; c += n_waves) {
         const uint32_t v = c * RT_WAVE + lane;
-        const bool active = v < n_rays;
+        bool active = v < n_rays;
         uint32_t gi = 0;
         RayRec rr;
         rr.ray.o = rr.ray.d = mk(0, 0, 0);
@@ -555,6 +622,120 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_setup(const DScene S, con
         const unsigned long long tc1 = clock64();
         ts[3] += tc1 - tc0;
 #endif
+        // Rays this kernel does not handle go to rt_setup_slow: non-finite components (the reference's exact order
+        // matters for them), directions far from unit length or origins so far out that a local ray could
+        // overflow (instance matrices of a cullable scene are below 1e15), or an instance without a culling box.
+        const float o_l1 = fabsf(r.o.x) + fabsf(r.o.y) + fabsf(r.o.z);
+        const bool easy = finite3(r.o) && finite3(r.d) && fabsf(r.d.x) + fabsf(r.d.y) + fabsf(r.d.z) < 4.0f &&
+                          S.all_cullable != 0 && o_l1 < 1e15f;
+        {
+            const uint32_t slot = append_slot(active && !easy, &slow_n, F.seg_rays, F.n_seg, F.slow_counts, F.ovf_rays, F.overflow, lane);
+            if (slot != RT_REF_NONE) F.slow_rays[slot] = gi;
+        }
+        active = active && easy;
+        const bool early = ss.is_shadow;
+
+        // planes, spheres, triangles: intersect.rs:20-36 per kind, merged as scene.rs:129-131
+        bool have = false; float best_t = 0.0f; uint32_t best_order = 0;
+        bool settled = false;
+        if (active) {
+            if (staged) analytic_hits(S, ld_planes, ld_spheres, ld_triangles, r, early, ss, have, best_t, best_order, settled);
+            else analytic_hits(S, S.planes, S.spheres, S.triangles, r, early, ss, have, best_t, best_order, settled);
+        }
+#ifdef RT_STATS
+        const unsigned long long tc2 = clock64();
+        ts[4] += tc2 - tc1;
+#endif
+        // mesh instances in Vec order (scene.rs:133-136): only decide whether the ray can touch the instance at all,
+        // within the distance that still matters; the local ray and the exact root test are rt_root's business
+        const V3 inv_w = mk(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+        float lw = ss.limit_world;
+        if (have && best_t < lw) lw = best_t;
+        const float lw_cut = lw * 1.000244140625f;
+        for (uint32_t ii = 0; ii < S.n_instances; ++ii) {
+            const DInstance& inst = S.instances[ii];
+            bool want_item = false;
+            if (active && !settled && inst.root_ref != RT_REF_NONE) {
+                // the box is only trusted for origins within cull_origin_limit; farther rays always get a work item
+                float tmin_w;
+                want_item = !(o_l1 < inst.cull_origin_limit) ||
+                            (slab(inst.world_lo[0], inst.world_lo[1], inst.world_lo[2], inst.world_hi[0], inst.world_hi[1],
+                                  inst.world_hi[2], r.o, inv_w, tmin_w) && !(tmin_w > lw_cut));
+            }
+            uint32_t slot = append_slot(want_item, &out_n, F.seg_items, F.n_seg, F.item_counts, F.ovf_items, F.overflow, lane);
+            if (slot != RT_REF_NONE) F.items[slot] = make_uint2(gi, ii);
+        }
+#ifdef RT_STATS
+        const unsigned long long tc3 = clock64();
+        ts[5] += tc3 - tc2;
+#endif
+        if (active) F.best[gi] = have ? make_key(best_t, best_order) : RT_KEY_NONE;
+#ifdef RT_STATS
+        ts[6] += clock64() - tc3;
+#endif
+    }
+#ifdef RT_STATS
+    ts[0] = clock64() - ts_begin;
+    if (lane == 0 && gwave < 8192) for (int k = 0; k < 8; ++k) g_setup_timing[gwave * 8 + k] = ts[k];
+#endif
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        F.item_counts[blockIdx.x] = out_n < F.seg_items ? out_n : F.seg_items;
+        F.slow_counts[blockIdx.x] = slow_n < F.seg_rays ? slow_n : F.seg_rays;
+        if (slow_n) F.slow_flags[level] = 1u;
+    }
+}
+
+// ======================================================================================================
+// Kernel A': the rays rt_setup handed over (none, for ordinary scenes).  Everything Scene::intersect does for
+// such a ray except the BVH walks of finite local rays: analytic primitives, per instance the local ray
+// (intersect.rs:296-308) and either the whole walk in the reference's own order (a ray with a non-finite
+// component) or the exact root test -> BVH work item.
+// ======================================================================================================
+__global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_setup_slow(const DScene S, const DFrame F, const uint32_t level) {
+    if (F.slow_flags[level] == 0) return;                          // the usual case: rt_setup kept every ray
+    extern __shared__ uint32_t lds[];
+    uint32_t* pre = lds;                       // n_seg + 1
+    uint32_t* scratch = lds + F.n_seg + 1;     // blockDim.x
+    __shared__ uint32_t out_n;
+    if (threadIdx.x == 0) out_n = F.item_counts[blockIdx.x];        // this block's segment continues where rt_setup stopped
+    const uint32_t p = level & 1;
+    const uint32_t n_rays = build_prefix(F.slow_counts, F.n_seg, F.seg_rays, F.ovf_rays, pre, scratch);
+    // the analytic primitives are staged in LDS (every lane reads the same one: a broadcast, no scalar-load
+    // round trip per primitive)
+    uint32_t* stage = lds + F.n_seg + 1 + blockDim.x;
+    const uint32_t stage_words = analytic_stage_words(S);
+    const bool staged = stage_words != 0;
+    const uint32_t plane_words = S.n_planes * (sizeof(DPlane) / 4), sphere_words = S.n_spheres * (sizeof(DSphere) / 4);
+    const DPlane* ld_planes = (const DPlane*)stage;
+    const DSphere* ld_spheres = (const DSphere*)(stage + plane_words);
+    const DTriangle* ld_triangles = (const DTriangle*)(stage + plane_words + sphere_words);
+    if (staged) {
+        for (uint32_t w = threadIdx.x; w < stage_words; w += blockDim.x) {
+            uint32_t v;
+            if (w < plane_words) v = ((const uint32_t*)S.planes)[w];
+            else if (w < plane_words + sphere_words) v = ((const uint32_t*)S.spheres)[w - plane_words];
+            else v = ((const uint32_t*)S.triangles)[w - plane_words - sphere_words];
+            stage[w] = v;
+        }
+        __syncthreads();
+    }
+    const float4* rays = F.rays[p];
+    const uint32_t lane = threadIdx.x & (RT_WAVE - 1);
+    const uint32_t gwave = (blockIdx.x * blockDim.x + threadIdx.x) / RT_WAVE;
+    const uint32_t n_waves = gridDim.x * (RT_BLOCK_THREADS / RT_WAVE);
+
+    for (uint32_t c = gwave; (unsigned long long)c * RT_WAVE < n_rays; c += n_waves) {
+        const uint32_t v = c * RT_WAVE + lane;
+        const bool active = v < n_rays;
+        uint32_t gi = 0;
+        RayRec rr;
+        rr.ray.o = rr.ray.d = mk(0, 0, 0);
+        rr.throughput = 0.0f;
+        rr.meta = 0;
+        if (active) { gi = F.slow_rays[locate(pre, F.n_seg, F.seg_rays, v)]; rr = load_rec(rays, gi); }
+        const Ray r = rr.ray;
+        const ShadowSpec ss = shadow_spec(S, rr);
         const bool ray_finite = finite3(r.o) && finite3(r.d);
         const bool early = ss.is_shadow && (ss.directional || ray_finite);
 
@@ -562,42 +743,10 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_setup(const DScene S, con
         bool have = false; float best_t = 0.0f; uint32_t best_order = 0;
         bool settled = false;
         if (active) {
-            {
-                bool g_have = false; float g_t = 0.0f; uint32_t g_i = 0;
-                for (uint32_t i = 0; i < S.n_planes; ++i) {
-                    float t;
-                    if (plane_t(S.planes[i], r, t) && closer(g_have, g_t, t)) { g_have = true; g_t = t; g_i = i; }
-                }
-                if (g_have && closer(have, best_t, g_t)) { have = true; best_t = g_t; best_order = analytic_order(RT_PRIM_PLANE, g_i); }
-            }
-            settled = early && have && (ss.directional || best_t < ss.limit_world);
-            if (!settled) {
-                bool g_have = false; float g_t = 0.0f; uint32_t g_i = 0;
-                for (uint32_t i = 0; i < S.n_spheres; ++i) {
-                    float t;
-                    if (sphere_t(S.spheres[i], r, t) && closer(g_have, g_t, t)) { g_have = true; g_t = t; g_i = i; }
-                }
-                if (g_have && closer(have, best_t, g_t)) { have = true; best_t = g_t; best_order = analytic_order(RT_PRIM_SPHERE, g_i); }
-                settled = early && have && (ss.directional || best_t < ss.limit_world);
-            }
-            if (!settled) {
-                bool g_have = false; float g_t = 0.0f; uint32_t g_i = 0;
-                for (uint32_t i = 0; i < S.n_triangles; ++i) {
-                    const DTriangle& tr = S.triangles[i];
-                    float t, u, w;
-                    if (triangle_tuv(ld3(tr.p0), ld3(tr.e1), ld3(tr.e2), r, t, u, w) && closer(g_have, g_t, t)) {
-                        g_have = true; g_t = t; g_i = i;
-                    }
-                }
-                if (g_have && closer(have, best_t, g_t)) { have = true; best_t = g_t; best_order = analytic_order(RT_PRIM_TRIANGLE, g_i); }
-                settled = early && have && (ss.directional || best_t < ss.limit_world);
-            }
+            if (staged) analytic_hits(S, ld_planes, ld_spheres, ld_triangles, r, early, ss, have, best_t, best_order, settled);
+            else analytic_hits(S, S.planes, S.spheres, S.triangles, r, early, ss, have, best_t, best_order, settled);
         }
 
-#ifdef RT_STATS
-        const unsigned long long tc2 = clock64();
-        ts[4] += tc2 - tc1;
-#endif
         // mesh instances in Vec order (scene.rs:133-136)
         const float o_l1 = fabsf(r.o.x) + fabsf(r.o.y) + fabsf(r.o.z);
         bool exact_mesh = false;             // exact path: the winner so far is a mesh triangle
@@ -644,10 +793,6 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_setup(const DScene S, con
             uint32_t slot = append_slot(want_item, &out_n, F.seg_items, F.n_seg, F.item_counts, F.ovf_items, F.overflow, lane);
             if (slot != RT_REF_NONE) F.items[slot] = make_uint2(gi, ii);
         }
-#ifdef RT_STATS
-        const unsigned long long tc3 = clock64();
-        ts[5] += tc3 - tc2;
-#endif
         // a mesh winner found on the exact path is recorded as a finished work item
         {
             uint32_t slot = append_slot(active && exact_mesh, &out_n, F.seg_items, F.n_seg, F.item_counts, F.ovf_items, F.overflow, lane);
@@ -667,16 +812,78 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_setup(const DScene S, con
                                                         : (((unsigned long long)__float_as_uint(best_t) << 32) | best_order);
             F.best[gi] = key;
         }
-#ifdef RT_STATS
-        ts[6] += clock64() - tc3;
-#endif
     }
-#ifdef RT_STATS
-    ts[0] = clock64() - ts_begin;
-    if (lane == 0 && gwave < 8192) for (int k = 0; k < 8; ++k) g_setup_timing[gwave * 8 + k] = ts[k];
-#endif
     __syncthreads();
     if (threadIdx.x == 0) F.item_counts[blockIdx.x] = out_n < F.seg_items ? out_n : F.seg_items;
+}
+
+// ======================================================================================================
+// Kernel A2: per BVH work item, the mesh-local ray of intersect.rs:296-308 and the test of the mesh's root box
+// (the first iteration of intersect.rs:245-250).  Items that pass become 64-byte entries (see RT_FAT_FAST in
+// rt_device.h) the walk can start from with one fetch.
+// ======================================================================================================
+__global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_root(const DScene S, const DFrame F, const uint32_t level) {
+    extern __shared__ uint32_t lds[];
+    uint32_t* pre = lds;
+    uint32_t* scratch = lds + F.n_seg + 1;
+    __shared__ uint32_t out_n;
+    if (threadIdx.x == 0) out_n = 0;
+    const uint32_t n_items = build_prefix(F.item_counts, F.n_seg, F.seg_items, F.ovf_items, pre, scratch);
+    const float4* rays = F.rays[level & 1];
+    const uint32_t lane = threadIdx.x & (RT_WAVE - 1);
+    const uint32_t gwave = (blockIdx.x * blockDim.x + threadIdx.x) / RT_WAVE;
+    const uint32_t n_waves = gridDim.x * (RT_BLOCK_THREADS / RT_WAVE);
+    for (uint32_t c = gwave; (unsigned long long)c * RT_WAVE < n_items; c += n_waves) {
+        const uint32_t v = c * RT_WAVE + lane;
+        bool pass = false;
+        float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
+        if (v < n_items) {
+            const uint32_t item = locate(pre, F.n_seg, F.seg_items, v);
+            const uint2 it = F.items[item];
+            if (!(it.y & RT_ITEM_DONE)) {
+                const uint32_t gi = it.x, ii = it.y;
+                const RayRec rr = load_rec(rays, gi);
+                const ShadowSpec ss = shadow_spec(S, rr);
+                const DInstance& inst = S.instances[ii];
+                const float o_l1 = fabsf(rr.ray.o.x) + fabsf(rr.ray.o.y) + fabsf(rr.ray.o.z);
+                Ray lr;
+                lr.o = transform34(inst.model_inverse, rr.ray.o);
+                V3 dv = transform34(inst.rotation_scale_inverse, rr.ray.d);
+                const float dn = sqrtf(dot3(dv, dv));
+                lr.d = mk(dv.x / dn, dv.y / dn, dv.z / dn);                 // glm::normalize, intersect.rs:304-308
+                const V3 inv = mk(1.0f / lr.d.x, 1.0f / lr.d.y, 1.0f / lr.d.z);
+                const bool fast = inst.prunable != 0;
+                const float slack_w = 2.0f * inst.world_guard;
+                // mesh-local bound on useful t: a hit at world distance w lies at local t = w * dn (up to world_guard)
+                float limit = RT_INF;
+                if (fast) {
+                    float lw = ss.limit_world;
+                    const unsigned long long key = F.best[gi];
+                    if (key != RT_KEY_NONE) { float bt = __uint_as_float((uint32_t)(key >> 32)); if (bt < lw) lw = bt; }
+                    if (lw < RT_INF) limit = (lw + slack_w + 1.52587890625e-05f * (o_l1 + lw)) * dn * 1.0009765625f;
+                }
+                float root_tmin;
+                pass = slab(inst.root_lo[0], inst.root_lo[1], inst.root_lo[2], inst.root_hi[0], inst.root_hi[1], inst.root_hi[2],
+                            lr.o, inv, root_tmin);
+                if (pass && fast && root_tmin > limit * RT_PRUNE_REL + inst.prune_abs) pass = false;
+                // Shadow rays: a candidate at local t lies within world_guard of world distance t / dn, and the pair's
+                // final hit is not farther than any candidate.
+                float thr = -RT_INF;
+                if (ss.is_shadow) thr = ss.directional ? RT_INF : ss.limit_world - (1.5f * slack_w + 6.103515625e-05f * (o_l1 + ss.limit_world));
+                q0 = make_float4(lr.o.x, lr.o.y, lr.o.z, root_tmin);
+                q1 = make_float4(lr.d.x, lr.d.y, lr.d.z, limit);
+                q2 = make_float4(1.0f / dn, thr, inst.prune_abs, __uint_as_float(inst.root_ref));
+                q3 = make_float4(__uint_as_float(gi), __uint_as_float(ii | (fast ? RT_FAT_FAST : 0u)), __uint_as_float(item), 0.0f);
+            }
+        }
+        const uint32_t slot = append_slot(pass, &out_n, F.seg_fat, F.n_seg, F.fat_counts, F.ovf_fat, F.overflow, lane);
+        if (slot != RT_REF_NONE) {
+            F.fat_items[4 * (size_t)slot] = q0; F.fat_items[4 * (size_t)slot + 1] = q1;
+            F.fat_items[4 * (size_t)slot + 2] = q2; F.fat_items[4 * (size_t)slot + 3] = q3;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) F.fat_counts[blockIdx.x] = out_n < F.seg_fat ? out_n : F.seg_fat;
 }
 
 // ======================================================================================================
@@ -702,7 +909,7 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
     extern __shared__ uint32_t lds[];
     uint32_t* pre = lds;
     uint32_t* scratch = lds + F.n_seg + 1;
-    const uint32_t n_items = build_prefix(F.item_counts, F.n_seg, F.seg_items, F.ovf_items, pre, scratch);
+    const uint32_t n_items = build_prefix(F.fat_counts, F.n_seg, F.seg_fat, F.ovf_fat, pre, scratch);
     const uint32_t lane = threadIdx.x & (RT_WAVE - 1);
     const uint32_t wave = threadIdx.x / RT_WAVE;
     uint32_t* wave_stack = lds + F.n_seg + 1 + blockDim.x + wave * (2 * S.stack_entries * RT_WAVE);
@@ -730,9 +937,9 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
     bool pending = false;           // walk finished, its part in the pair's result not yet settled
     uint32_t item = 0, gi = 0, ii = 0, sp = 0, base = 0, owner = lane;
     Ray lr; lr.o = lr.d = mk(0, 0, 0);
-    V3 inv = mk(0, 0, 0), world_o = mk(0, 0, 0);
-    bool fast = false, early = false, directional = false;
-    float limit = RT_INF, prune_abs = 0.0f, slack_w = 0.0f, limit_world = RT_INF, o_l1 = 0.0f, inv_dn = 0.0f;
+    V3 inv = mk(0, 0, 0);
+    bool fast = false;
+    float limit = RT_INF, prune_abs = 0.0f, shadow_thr = -RT_INF, inv_dn = 0.0f;
     bool m_have = false; float m_t = 0.0f, m_u = 0.0f, m_v = 0.0f; uint32_t m_slot = 0;
 #ifdef RT_STATS
     uint32_t dbg_steps = 0;
@@ -777,7 +984,8 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
                             triangle_tuv(mk(h0.x, h0.y, h0.z), mk(h0.w, h1.x, h1.y), mk(h1.z, h1.w, h2.x), lr, m_t, m_u, m_v);
                             m_slot = win_slot;
                         }
-                        float tw = world_t(S, S.instances[ii], lr, world_o, m_t, m_slot);
+                        const float4 w0 = rays[2 * (size_t)gi];                  // the ray's world origin
+                        float tw = world_t(S, S.instances[ii], lr, mk(w0.x, w0.y, w0.z), m_t, m_slot);
                         F.item_results[item] = make_float4(m_t, m_u, m_v, __uint_as_float(m_slot));
                         atomicMin(&F.best[gi], make_key(tw, RT_KEY_MESH | item));
                     }
@@ -806,54 +1014,26 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
             if (!running) {
                 const uint32_t rank = __popcll(idle_mask & ((1ull << lane) - 1ull));
                 if (rank < avail) {
-                    item = locate(pre, F.n_seg, F.seg_items, chunk_next + rank);
-                    const uint2 it = F.items[item];
-#ifdef RT_STATS
-                    F.items[item].x = 0;
-#endif
-                    if (!(it.y & RT_ITEM_DONE)) {
-                        gi = it.x; ii = it.y;
-                        const RayRec rr = load_rec(rays, gi);
-                        const ShadowSpec ss = shadow_spec(S, rr);
-                        const DInstance& inst = S.instances[ii];
-                        world_o = rr.ray.o;
-                        o_l1 = fabsf(world_o.x) + fabsf(world_o.y) + fabsf(world_o.z);
-                        lr.o = transform34(inst.model_inverse, rr.ray.o);
-                        V3 dv = transform34(inst.rotation_scale_inverse, rr.ray.d);
-                        float dn = sqrtf(dot3(dv, dv));
-                        lr.d = mk(dv.x / dn, dv.y / dn, dv.z / dn);
-                        inv = mk(1.0f / lr.d.x, 1.0f / lr.d.y, 1.0f / lr.d.z);
-                        inv_dn = 1.0f / dn;
-                        fast = inst.prunable != 0;
-                        early = ss.is_shadow;
-                        directional = ss.directional;
-                        limit_world = ss.limit_world;
-                        slack_w = 2.0f * inst.world_guard;
-                        prune_abs = inst.prune_abs;
-                        // mesh-local bound on useful t: a hit at world distance w lies at local t = w * dn (up to
-                        // world_guard).  F.best only ever decreases, so any value read here is a valid bound.
-                        limit = RT_INF;
-                        if (fast) {
-                            float lw = limit_world;
-                            const unsigned long long key = F.best[gi];
-                            if (key != RT_KEY_NONE) { float bt = __uint_as_float((uint32_t)(key >> 32)); if (bt < lw) lw = bt; }
-                            if (lw < RT_INF) limit = (lw + slack_w + 1.52587890625e-05f * (o_l1 + lw)) * dn * 1.0009765625f;
-                        }
-                        float root_tmin;
-                        bool pass = slab(inst.root_lo[0], inst.root_lo[1], inst.root_lo[2], inst.root_hi[0], inst.root_hi[1],
-                                         inst.root_hi[2], lr.o, inv, root_tmin);
-                        if (pass && fast && root_tmin > limit * RT_PRUNE_REL + prune_abs) pass = false;
-                        if (pass) {
-                            m_have = false; m_t = 0.0f; m_u = 0.0f; m_v = 0.0f; m_slot = 0;
-                            stack[0] = inst.root_ref;
-                            stack_t[0] = __float_as_uint(root_tmin);
-                            sp = 1; base = 0;
-                            owner = lane;
-                            recs[4 * lane] = 0xFFFFFFFFu; recs[4 * lane + 1] = 0xFFFFFFFFu;
-                            recs[4 * lane + 2] = 1u; recs[4 * lane + 3] = 0u;
-                            running = true;
-                        }
-                    }
+                    const size_t fat = locate(pre, F.n_seg, F.seg_fat, chunk_next + rank);
+                    const float4 q0 = F.fat_items[4 * fat], q1 = F.fat_items[4 * fat + 1], q2 = F.fat_items[4 * fat + 2],
+                                 q3 = F.fat_items[4 * fat + 3];
+                    lr.o = mk(q0.x, q0.y, q0.z);
+                    lr.d = mk(q1.x, q1.y, q1.z);
+                    inv = mk(1.0f / lr.d.x, 1.0f / lr.d.y, 1.0f / lr.d.z);
+                    limit = q1.w;
+                    inv_dn = q2.x; shadow_thr = q2.y; prune_abs = q2.z;
+                    gi = __float_as_uint(q3.x);
+                    ii = __float_as_uint(q3.y) & ~RT_FAT_FAST;
+                    fast = (__float_as_uint(q3.y) & RT_FAT_FAST) != 0;
+                    item = __float_as_uint(q3.z);
+                    m_have = false; m_t = 0.0f; m_u = 0.0f; m_v = 0.0f; m_slot = 0;
+                    stack[0] = __float_as_uint(q2.w);
+                    stack_t[0] = __float_as_uint(q0.w);
+                    sp = 1; base = 0;
+                    owner = lane;
+                    recs[4 * lane] = 0xFFFFFFFFu; recs[4 * lane + 1] = 0xFFFFFFFFu;
+                    recs[4 * lane + 2] = 1u; recs[4 * lane + 3] = 0u;
+                    running = true;
                 }
             }
             chunk_next += asking < avail ? asking : avail;
@@ -871,20 +1051,18 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
                 }
                 uint32_t src = lane;
                 if (taking) src = donor_list[idle_rank];
-                const uint32_t flags = (fast ? 1u : 0u) | (early ? 2u : 0u) | (directional ? 4u : 0u);
                 const float ox = __shfl(lr.o.x, src), oy = __shfl(lr.o.y, src), oz = __shfl(lr.o.z, src);
                 const float dx = __shfl(lr.d.x, src), dy = __shfl(lr.d.y, src), dz = __shfl(lr.d.z, src);
-                const float wx = __shfl(world_o.x, src), wy = __shfl(world_o.y, src), wz = __shfl(world_o.z, src);
-                const float s_limit = __shfl(limit, src), s_prune = __shfl(prune_abs, src), s_slack = __shfl(slack_w, src);
-                const float s_lw = __shfl(limit_world, src), s_l1 = __shfl(o_l1, src), s_idn = __shfl(inv_dn, src);
+                const float s_limit = __shfl(limit, src), s_prune = __shfl(prune_abs, src), s_thr = __shfl(shadow_thr, src);
+                const float s_idn = __shfl(inv_dn, src);
                 const uint32_t s_item = __shfl(item, src), s_gi = __shfl(gi, src), s_ii = __shfl(ii, src);
-                const uint32_t s_owner = __shfl(owner, src), s_flags = __shfl(flags, src), s_base = __shfl(base, src);
-                if (taking) {
-                    lr.o = mk(ox, oy, oz); lr.d = mk(dx, dy, dz); world_o = mk(wx, wy, wz);
+                const uint32_t s_owner = __shfl(owner, src), s_base = __shfl(base, src);
+                if (taking) {                                                  // only `fast` walks are shared
+                    lr.o = mk(ox, oy, oz); lr.d = mk(dx, dy, dz);
                     inv = mk(1.0f / lr.d.x, 1.0f / lr.d.y, 1.0f / lr.d.z);
-                    limit = s_limit; prune_abs = s_prune; slack_w = s_slack; limit_world = s_lw; o_l1 = s_l1; inv_dn = s_idn;
+                    limit = s_limit; prune_abs = s_prune; shadow_thr = s_thr; inv_dn = s_idn;
                     item = s_item; gi = s_gi; ii = s_ii; owner = s_owner;
-                    fast = (s_flags & 1u) != 0; early = (s_flags & 2u) != 0; directional = (s_flags & 4u) != 0;
+                    fast = true;
                     m_have = false; m_t = 0.0f; m_u = 0.0f; m_v = 0.0f; m_slot = 0;
                     stack[0] = wave_stack[s_base * RT_WAVE + src];
                     stack_t[0] = wave_stack[(S.stack_entries + s_base) * RT_WAVE + src];
@@ -964,9 +1142,8 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
 #endif
                     if (improved) {
                         atomicMin((unsigned long long*)&recs[4 * owner], make_key(m_t, m_slot));
-                        // Does this candidate already prove "shadow"?  The pair's final hit has a local t that is not
-                        // larger, and a hit at local t lies within world_guard of world distance t / dn.
-                        if (early && (directional || m_t * inv_dn < limit_world - (1.5f * slack_w + 6.103515625e-05f * (o_l1 + limit_world)))) {
+                        // does this candidate already prove a shadow ray blocked (see rt_root)?
+                        if (m_t * inv_dn < shadow_thr) {
                             sp = base;
                             recs[4 * owner + 3] = 1u;
                         }
@@ -1253,6 +1430,8 @@ __global__ void rt_level_reset(const DFrame F, uint32_t level) {
     const uint32_t p = level & 1, last = F.n_seg - 1;
     F.ray_counts[p ^ 1][last] = 0;
     F.item_counts[last] = 0;
+    F.fat_counts[last] = 0;
+    F.slow_counts[last] = 0;
     F.hit_counts[p][last] = 0;
 }
 
@@ -1346,7 +1525,7 @@ extern "C" hipError_t rt_launch_generate(const DFrame* F, uint32_t blocks, hipSt
 
 // One recursion depth: A, B, C and (from depth 1 on) D.  `blocks` is the grid of the list-producing
 // kernels (F->n_seg - 1), `traverse_blocks` that of the BVH walk.
-// `marks`, when not null, are five events recorded before A and after A, B, C and D (kernel timing mode).
+// `marks`, when not null, are six events recorded before A and after A, A2, B, C and D (kernel timing mode).
 extern "C" hipError_t rt_launch_level(const DScene* S, const DFrame* F, uint32_t level, uint32_t blocks,
                                       uint32_t traverse_blocks, hipStream_t stream, hipEvent_t* marks) {
     const size_t lds = list_lds_bytes(F->n_seg);
@@ -1356,20 +1535,26 @@ extern "C" hipError_t rt_launch_level(const DScene* S, const DFrame* F, uint32_t
 #endif
     hipLaunchKernelGGL(rt_level_reset, dim3(1), dim3(1), 0, stream, *F, level);
     if (marks) (void)hipEventRecord(marks[0], stream);
-    hipLaunchKernelGGL(rt_setup, dim3(blocks), dim3(RT_BLOCK_THREADS), lds, stream, *S, *F, level);
+    hipLaunchKernelGGL(rt_setup, dim3(blocks), dim3(RT_BLOCK_THREADS), lds + analytic_stage_words(*S) * sizeof(uint32_t), stream, *S,
+                       *F, level);
+    hipLaunchKernelGGL(rt_setup_slow, dim3(blocks), dim3(RT_BLOCK_THREADS), lds + analytic_stage_words(*S) * sizeof(uint32_t), stream,
+                       *S, *F, level);
     if (marks) (void)hipEventRecord(marks[1], stream);
+    if (S->n_instances > 0)
+        hipLaunchKernelGGL(rt_root, dim3(blocks), dim3(RT_BLOCK_THREADS), lds, stream, *S, *F, level);
+    if (marks) (void)hipEventRecord(marks[2], stream);
     if (S->n_instances > 0)
         hipLaunchKernelGGL(rt_traverse, dim3(traverse_blocks), dim3(RT_BLOCK_THREADS), traverse_lds_bytes(F->n_seg, S->stack_entries),
                            stream, *S, *F, level);
 #ifdef RT_STATS
     if (stop && level == (uint32_t)atoi(stop)) return hipGetLastError();
 #endif
-    if (marks) (void)hipEventRecord(marks[2], stream);
-    hipLaunchKernelGGL(rt_shade, dim3(blocks), dim3(RT_BLOCK_THREADS), lds, stream, *S, *F, level);
     if (marks) (void)hipEventRecord(marks[3], stream);
+    hipLaunchKernelGGL(rt_shade, dim3(blocks), dim3(RT_BLOCK_THREADS), lds, stream, *S, *F, level);
+    if (marks) (void)hipEventRecord(marks[4], stream);
     if (level > 0 && S->n_lights > 0)
         hipLaunchKernelGGL(rt_phong, dim3(blocks), dim3(RT_BLOCK_THREADS), lds, stream, *S, *F, level);
-    if (marks) (void)hipEventRecord(marks[4], stream);
+    if (marks) (void)hipEventRecord(marks[5], stream);
     return hipGetLastError();
 }
 

@@ -37,12 +37,31 @@ class RtError(RuntimeError):
         self.code = code
 
 
+def _share_torch_hip_runtime():
+    """PyTorch's ROCm wheel ships its own libamdhip64.so / libhsa-runtime64.so.  A process that first
+    loads the system copies (through librt_hip.so) and later imports torch ends up with two ROCm
+    runtimes, and the second one to initialise may find "no ROCm-capable device".  When torch is
+    installed, its copy is therefore loaded first; librt_hip.so's dependency on libamdhip64.so.7 then
+    resolves to that already loaded object, whichever of the two is imported first by the caller."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     global _LIB
     if _LIB is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("%s is missing - build it with __graft_entry__.build() or make -C rust_raytracer_amd/csrc"
                                % LIB_PATH)
+        _share_torch_hip_runtime()
         L = C.CDLL(LIB_PATH)
         vp, u32 = C.c_void_p, C.c_uint32
         L.rt_scene_create.argtypes = [C.POINTER(abi.RtSceneDesc), C.c_int, C.POINTER(vp)]
@@ -164,15 +183,15 @@ class DeviceScene:
         check(lib().rt_last_trace_ms(self._h, C.byref(ms)))
         return float(ms.value)
 
-    LEVEL_KERNELS = ("rt_setup", "rt_traverse", "rt_shade", "rt_phong")
+    LEVEL_KERNELS = ("rt_setup", "rt_root", "rt_traverse", "rt_shade", "rt_phong")
 
     def set_kernel_timing(self, enable: bool):
         check(lib().rt_set_kernel_timing(self._h, 1 if enable else 0))
 
     def last_kernel_ms(self) -> dict:
         """{kernel name: (summed ms, launches)} of the last frame rendered in kernel timing mode."""
-        ms = (C.c_float * 4)()
-        n = (C.c_uint32 * 4)()
+        ms = (C.c_float * len(self.LEVEL_KERNELS))()
+        n = (C.c_uint32 * len(self.LEVEL_KERNELS))()
         check(lib().rt_last_kernel_ms(self._h, ms, n))
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(self.LEVEL_KERNELS)}
 

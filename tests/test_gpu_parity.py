@@ -143,7 +143,7 @@ def test_tile_shards_assemble_to_the_same_frame(scenes_dir, model_dir, shards):
         for r in range(shards):
             part = gathered[r * nbytes:(r + 1) * nbytes]
             dev.render_device(part.data_ptr(), shard_index=r, shard_count=shards, stream=stream)
-            torch.cuda.synchronize()
+            dev.last_ray_counts()                  # raises if a ray list overflowed (the frame would be incomplete)
             assert np.array_equal(part.cpu().numpy(), sharding.extract_shard(whole, r, shards))
         frame = torch.zeros(h * w * 3, dtype=torch.uint8, device="cuda")
         dev.assemble_shards(gathered.data_ptr(), frame.data_ptr(), shards, stream=stream)
