@@ -70,6 +70,7 @@ struct RtScene {
     size_t aux_out_pixels = 0;
     uint32_t debug_queue_capacity = 0;
     size_t stats_words = 0;
+    size_t pixel_clear_bytes = 0, counter_words = 0;
     // kernel timing mode (rt_set_kernel_timing): six events per recursion depth
     bool kernel_timing = false;
     std::vector<hipEvent_t> marks;
@@ -481,19 +482,29 @@ static int ensure_frame(RtScene* s, const Geometry& g, uint32_t max_depth, bool 
         const size_t flag_bytes = hit_slots * (s->d.n_lights ? s->d.n_lights : 1);
         s->stats_words = (size_t)blocks * 4 * 8;
         int rc;
-        if ((rc = frame_alloc(s, (size_t)3 * g.n_pixels, &f.acc)) || (rc = frame_alloc(s, g.n_pixels, &f.poison)) ||
+        // colour sums and poison words in one allocation, all counters in another: two clears per frame
+        long long* pixels = nullptr;
+        unsigned int* counters = nullptr;
+        s->pixel_clear_bytes = (size_t)3 * g.n_pixels * sizeof(long long) + (size_t)g.n_pixels * sizeof(unsigned int);
+        s->counter_words = 7 * (size_t)f.n_seg + 2 * (RT_MAX_DEPTH_LIMIT + 2) + s->stats_words;
+        if ((rc = frame_alloc(s, s->pixel_clear_bytes / sizeof(long long) + 1, &pixels)) ||
+            (rc = frame_alloc(s, s->counter_words, &counters)) ||
             (rc = frame_alloc(s, 2 * ray_slots, &f.rays[0])) || (rc = frame_alloc(s, 2 * ray_slots, &f.rays[1])) ||
-            (rc = frame_alloc(s, f.n_seg, &f.ray_counts[0])) || (rc = frame_alloc(s, f.n_seg, &f.ray_counts[1])) ||
             (rc = frame_alloc(s, ray_slots, &f.best)) ||
             (rc = frame_alloc(s, item_slots, &f.items)) || (rc = frame_alloc(s, item_slots, &f.item_results)) ||
-            (rc = frame_alloc(s, f.n_seg, &f.item_counts)) || (rc = frame_alloc(s, 4 * fat_slots, &f.fat_items)) ||
-            (rc = frame_alloc(s, f.n_seg, &f.fat_counts)) || (rc = frame_alloc(s, ray_slots, &f.slow_rays)) ||
-            (rc = frame_alloc(s, f.n_seg, &f.slow_counts)) || (rc = frame_alloc(s, RT_MAX_DEPTH_LIMIT + 2, &f.slow_flags)) || (rc = frame_alloc(s, RT_MAX_DEPTH_LIMIT + 2, &f.chunk_counter)) ||
+            (rc = frame_alloc(s, 4 * fat_slots, &f.fat_items)) || (rc = frame_alloc(s, ray_slots, &f.slow_rays)) ||
             (rc = frame_alloc(s, 3 * hit_slots, &f.hits[0])) || (rc = frame_alloc(s, 3 * hit_slots, &f.hits[1])) ||
-            (rc = frame_alloc(s, f.n_seg, &f.hit_counts[0])) || (rc = frame_alloc(s, f.n_seg, &f.hit_counts[1])) ||
-            (rc = frame_alloc(s, flag_bytes, &f.shadow_flags[0])) || (rc = frame_alloc(s, flag_bytes, &f.shadow_flags[1])) ||
-            (rc = frame_alloc(s, s->stats_words, &f.wave_stats)))
+            (rc = frame_alloc(s, flag_bytes, &f.shadow_flags[0])) || (rc = frame_alloc(s, flag_bytes, &f.shadow_flags[1])))
             return rc;
+        f.acc = pixels;
+        f.poison = reinterpret_cast<unsigned int*>(pixels + (size_t)3 * g.n_pixels);
+        unsigned int* c = counters;
+        f.ray_counts[0] = c; c += f.n_seg;   f.ray_counts[1] = c; c += f.n_seg;
+        f.item_counts = c; c += f.n_seg;     f.fat_counts = c; c += f.n_seg;     f.slow_counts = c; c += f.n_seg;
+        f.hit_counts[0] = c; c += f.n_seg;   f.hit_counts[1] = c; c += f.n_seg;
+        f.chunk_counter = c; c += RT_MAX_DEPTH_LIMIT + 2;
+        f.slow_flags = c; c += RT_MAX_DEPTH_LIMIT + 2;
+        f.wave_stats = c;
         if (aux && ((rc = frame_alloc(s, g.n_pixels, &f.aux_flags)) || (rc = frame_alloc(s, g.n_pixels, &f.aux_prim)) ||
                     (rc = frame_alloc(s, g.n_pixels, &f.aux_inst))))
             return rc;
@@ -528,12 +539,8 @@ static int enqueue_frame(RtScene* s, const RtRenderParams* p, bool sharded, bool
     DFrame f = s->f;
     if (!aux) f.aux_flags = f.aux_prim = f.aux_inst = nullptr;
     HIP_TRY(hipEventRecord(s->ev_start, stream));
-    HIP_TRY(hipMemsetAsync(f.acc, 0, (size_t)3 * g.n_pixels * sizeof(long long), stream));
-    HIP_TRY(hipMemsetAsync(f.poison, 0, (size_t)g.n_pixels * sizeof(unsigned int), stream));
-    HIP_TRY(hipMemsetAsync(f.wave_stats, 0, s->stats_words * sizeof(unsigned int), stream));
-    HIP_TRY(hipMemsetAsync(f.ray_counts[0], 0, f.n_seg * sizeof(unsigned int), stream));
-    HIP_TRY(hipMemsetAsync(f.chunk_counter, 0, (RT_MAX_DEPTH_LIMIT + 2) * sizeof(unsigned int), stream));
-    HIP_TRY(hipMemsetAsync(f.slow_flags, 0, (RT_MAX_DEPTH_LIMIT + 2) * sizeof(unsigned int), stream));
+    HIP_TRY(hipMemsetAsync(f.acc, 0, s->pixel_clear_bytes, stream));                              // colour sums + poison words
+    HIP_TRY(hipMemsetAsync(f.ray_counts[0], 0, s->counter_words * sizeof(unsigned int), stream));  // every counter + statistics
     if (aux) HIP_TRY(hipMemsetAsync(f.aux_flags, 0, (size_t)g.n_pixels * sizeof(unsigned int), stream));
     HIP_TRY(hipEventRecord(s->ev_trace_start, stream));
     HIP_TRY(rt_launch_generate(&f, s->list_blocks, stream));

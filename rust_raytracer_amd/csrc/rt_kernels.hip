@@ -349,33 +349,63 @@ __device__ __forceinline__ uint32_t analytic_order(uint32_t kind, uint32_t index
 
 // Exclusive prefix of the segment counts into `pre[0..n_seg]` (LDS); `scratch` is blockDim.x words of
 // LDS.  Block-wide: every thread of the block must call it.  Returns the total.
+// Each thread owns a run of consecutive segments; the runs are scanned inside each wave with lane shifts
+// and across the waves through `scratch`, so the whole thing costs two barriers.
+#define RT_PREFIX_RUN 8            // longest run a thread keeps in registers: 256 threads x 8 = 2048 segments
 __device__ uint32_t build_prefix(const unsigned int* counts, uint32_t n_seg, uint32_t seg_cap, uint32_t ovf_cap,
                                  uint32_t* pre, uint32_t* scratch) {
     const uint32_t t = threadIdx.x, nt = blockDim.x;
+    const uint32_t lane = t & (RT_WAVE - 1), wave = t / RT_WAVE, n_wave = nt / RT_WAVE;
     const uint32_t per = (n_seg + nt - 1) / nt;
     const uint32_t b0 = t * per;
     uint32_t sum = 0;
-    for (uint32_t i = b0; i < b0 + per && i < n_seg; ++i) {
-        uint32_t c = counts[i], cap = (i + 1 == n_seg) ? ovf_cap : seg_cap;
-        sum += c < cap ? c : cap;
+    uint32_t mine[RT_PREFIX_RUN];
+    if (per <= RT_PREFIX_RUN) {
+#pragma unroll
+        for (uint32_t k = 0; k < RT_PREFIX_RUN; ++k) {
+            const uint32_t i = b0 + k;
+            uint32_t c = 0;
+            if (k < per && i < n_seg) { c = counts[i]; const uint32_t cap = (i + 1 == n_seg) ? ovf_cap : seg_cap; c = c < cap ? c : cap; }
+            mine[k] = c;
+            sum += c;
+        }
+    } else {
+        for (uint32_t i = b0; i < b0 + per && i < n_seg; ++i) {
+            uint32_t c = counts[i], cap = (i + 1 == n_seg) ? ovf_cap : seg_cap;
+            sum += c < cap ? c : cap;
+        }
     }
-    scratch[t] = sum;
+    // inclusive scan of `sum` over the lanes of the wave
+    uint32_t incl = sum;
+#pragma unroll
+    for (uint32_t off = 1; off < RT_WAVE; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off);
+        if (lane >= off) incl += v;
+    }
+    if (lane == RT_WAVE - 1) scratch[wave] = incl;
     __syncthreads();
-    for (uint32_t off = 1; off < nt; off <<= 1) {
-        uint32_t v = t >= off ? scratch[t - off] : 0u;
-        __syncthreads();
-        scratch[t] += v;
-        __syncthreads();
+    uint32_t run = incl - sum, total = 0;
+    for (uint32_t w = 0; w < n_wave; ++w) {
+        const uint32_t v = scratch[w];
+        if (w < wave) run += v;
+        total += v;
     }
-    uint32_t run = scratch[t] - sum;
-    for (uint32_t i = b0; i < b0 + per && i < n_seg; ++i) {
-        uint32_t c = counts[i], cap = (i + 1 == n_seg) ? ovf_cap : seg_cap;
-        pre[i] = run;
-        run += c < cap ? c : cap;
+    if (per <= RT_PREFIX_RUN) {
+#pragma unroll
+        for (uint32_t k = 0; k < RT_PREFIX_RUN; ++k) {
+            const uint32_t i = b0 + k;
+            if (k < per && i < n_seg) { pre[i] = run; run += mine[k]; }
+        }
+    } else {
+        for (uint32_t i = b0; i < b0 + per && i < n_seg; ++i) {
+            uint32_t c = counts[i], cap = (i + 1 == n_seg) ? ovf_cap : seg_cap;
+            pre[i] = run;
+            run += c < cap ? c : cap;
+        }
     }
-    if (t == nt - 1) pre[n_seg] = scratch[nt - 1];
+    if (t == 0) pre[n_seg] = total;
     __syncthreads();
-    return pre[n_seg];
+    return total;
 }
 
 // Element v of the concatenated segments -> its slot in the backing array.
@@ -570,6 +600,9 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_setup(const DScene S, con
     __shared__ uint32_t out_n, slow_n;
     if (threadIdx.x == 0) { out_n = 0; slow_n = 0; }
     const uint32_t p = level & 1;
+    // the shared overflow segments of the lists rt_shade fills at this depth start empty (nothing reads or
+    // writes them before rt_shade)
+    if (blockIdx.x == 0 && threadIdx.x == 0) { F.ray_counts[p ^ 1][F.n_seg - 1] = 0; F.hit_counts[p][F.n_seg - 1] = 0; }
 #ifdef RT_STATS
     unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long ts_begin = clock64();
@@ -1214,6 +1247,10 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_shade(const DScene S, con
     __shared__ uint32_t out_rays, out_hits;
     if (threadIdx.x == 0) { out_rays = 0; out_hits = 0; }
     const uint32_t p = level & 1, q = p ^ 1;
+    // the shared overflow segments of the work-item lists are done for this depth and start empty at the next
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        F.item_counts[F.n_seg - 1] = 0; F.fat_counts[F.n_seg - 1] = 0; F.slow_counts[F.n_seg - 1] = 0;
+    }
     const uint32_t n_rays = build_prefix(F.ray_counts[p], F.n_seg, F.seg_rays, F.ovf_rays, pre, scratch);
     const float4* rays = F.rays[p];
     float4* rays_out = F.rays[q];
@@ -1425,16 +1462,6 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_phong(const DScene S, con
     }
 }
 
-// Zeroes the counters of the shared overflow segments that the coming depth will fill.
-__global__ void rt_level_reset(const DFrame F, uint32_t level) {
-    const uint32_t p = level & 1, last = F.n_seg - 1;
-    F.ray_counts[p ^ 1][last] = 0;
-    F.item_counts[last] = 0;
-    F.fat_counts[last] = 0;
-    F.slow_counts[last] = 0;
-    F.hit_counts[p][last] = 0;
-}
-
 // color.rs:42-52 + canvas layout.  One thread per local pixel.
 //  tiled == 0: row-major frame (bytes_per_pixel * width * height); padding pixels are skipped
 //  tiled == 1: this shard's tiles back to back, pixels row-major inside a tile, padding written as 0
@@ -1533,7 +1560,6 @@ extern "C" hipError_t rt_launch_level(const DScene* S, const DFrame* F, uint32_t
     const char* stop = getenv("RT_DEBUG_STOP_LEVEL");           // keep the lists of that depth as rt_traverse left them
     if (stop && level > (uint32_t)atoi(stop)) return hipSuccess;
 #endif
-    hipLaunchKernelGGL(rt_level_reset, dim3(1), dim3(1), 0, stream, *F, level);
     if (marks) (void)hipEventRecord(marks[0], stream);
     hipLaunchKernelGGL(rt_setup, dim3(blocks), dim3(RT_BLOCK_THREADS), lds + analytic_stage_words(*S) * sizeof(uint32_t), stream, *S,
                        *F, level);
