@@ -192,6 +192,14 @@ __device__ __forceinline__ bool slab(float lx, float ly, float lz, float hx, flo
 
 // Pruning slack, see trace_scene: relative part of every "is this box beyond the best hit" comparison.
 #define RT_PRUNE_REL 1.015625f            // 1 + 2^-6
+// Leaves are tested once RT_LEAF_BATCH lanes of a wave hold one, or one walking lane in RT_LEAF_SHARE
+// (measured on the 1080p bunnies frame: 16/4 2.02 ms, 32/2 1.71 ms, 48/2 1.72 ms of BVH walk per frame).
+#ifndef RT_LEAF_BATCH
+#define RT_LEAF_BATCH 32
+#endif
+#ifndef RT_LEAF_SHARE
+#define RT_LEAF_SHARE 2
+#endif
 
 // Full hitpoint of the winner.
 __device__ __forceinline__ Hitpoint finalize_hit(const DScene& S, const Ray& r, const Closest& c) {
@@ -969,6 +977,7 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
     bool running = false;           // walking a subtree of a pair
     bool pending = false;           // walk finished, its part in the pair's result not yet settled
     uint32_t item = 0, gi = 0, ii = 0, sp = 0, base = 0, owner = lane;
+    uint32_t pending_leaf = RT_REF_NONE;                            // a leaf this lane has reached and not yet tested
     Ray lr; lr.o = lr.d = mk(0, 0, 0);
     V3 inv = mk(0, 0, 0);
     bool fast = false;
@@ -1108,45 +1117,30 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
 #ifdef RT_STATS
         const unsigned long long t_walk = clock64();
         if (serviced) { tm[9] += t_walk - t_round; }
-        unsigned long long leaf_lanes = 0;
 #endif
-        // ---- one node per walking lane -----------------------------------------------------------------
-        if (running) {
+        // ---- leaves: a lane that has reached a leaf keeps it until a fair share of the walking lanes has one
+        // too, so that the triangle tests run on many lanes at once -------------------------------------------
+        {
+            const unsigned long long leaf_mask = __ballot(running && pending_leaf != RT_REF_NONE);
+            const uint32_t n_leaf = __popcll(leaf_mask), n_run = __popcll(run_mask);
+            if (n_leaf != 0 && (n_leaf >= RT_LEAF_BATCH || n_leaf * RT_LEAF_SHARE >= n_run)) {
 #ifdef RT_STATS
-            ++dbg_steps;
-            leaf_lanes = __ballot((stack[(sp - 1) * RT_WAVE] & RT_REF_LEAF_BIT) != 0);
+                tm[5] += 1; tm[6] += n_leaf;
+                const unsigned long long tl0 = clock64();
 #endif
-            --sp;
-            const uint32_t ref = stack[sp * RT_WAVE];
-            const float entry = __uint_as_float(stack_t[sp * RT_WAVE]);
-            const uint32_t pair_t = ((volatile uint32_t*)recs)[4 * owner + 1];     // closest hit any walker of the pair has
-            const uint32_t pair_done = ((volatile uint32_t*)recs)[4 * owner + 3];
-            float cut = RT_INF;                                      // boxes entered beyond this cannot matter
-            if (fast) {
-                float lim = (m_have && m_t < limit) ? m_t : limit;
-                if (pair_t != 0xFFFFFFFFu && __uint_as_float(pair_t) < lim) lim = __uint_as_float(pair_t);
-                cut = lim * RT_PRUNE_REL + prune_abs;
-            }
-#ifdef RT_STATS
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            tm[4] += clock64() - t_walk;        // pop
-#endif
-            if (pair_done) sp = base;                                // another walker has proven the shadow
-            else if (!(entry > cut)) {
-                if (ref & RT_REF_LEAF_BIT) {
-                    const uint32_t first = ref & RT_REF_SLOT_MASK;
-                    const uint32_t cnt = (ref >> RT_REF_COUNT_SHIFT) & 7u;
+                if (running && pending_leaf != RT_REF_NONE) {
+                    const uint32_t first = pending_leaf & RT_REF_SLOT_MASK;
+                    const uint32_t cnt = (pending_leaf >> RT_REF_COUNT_SHIFT) & 7u;
+                    pending_leaf = RT_REF_NONE;
                     bool improved = false;
-#ifdef RT_STATS
-                    const unsigned long long tl0 = clock64();
+                    // all of the leaf's triangles are fetched before the first test, so that the fetches overlap
+                    // (entries past the leaf's count repeat its last triangle and are not tested)
                     float4 h[RT_LEAF_TRIANGLES][3];
 #pragma unroll
                     for (uint32_t k = 0; k < RT_LEAF_TRIANGLES; ++k) {
-                        const uint32_t slot = first + (k < cnt ? k : (cnt ? cnt - 1 : 0));
-                        if (cnt) { h[k][0] = S.tri_hot[3 * slot]; h[k][1] = S.tri_hot[3 * slot + 1]; h[k][2] = S.tri_hot[3 * slot + 2]; }
+                        const uint32_t slot = first + (k < cnt ? k : cnt - 1);
+                        h[k][0] = S.tri_hot[3 * slot]; h[k][1] = S.tri_hot[3 * slot + 1]; h[k][2] = S.tri_hot[3 * slot + 2];
                     }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    const unsigned long long tl1 = clock64();
 #pragma unroll
                     for (uint32_t k = 0; k < RT_LEAF_TRIANGLES; ++k) {
                         const uint32_t slot = first + k;
@@ -1159,20 +1153,6 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
                             improved = true;
                         }
                     }
-                    const unsigned long long tl2 = clock64();
-                    tm[6] += tl1 - tl0; tm[7] += tl2 - tl1;
-#else
-                    for (uint32_t k = 0; k < cnt; ++k) {
-                        const uint32_t slot = first + k;
-                        float4 h0 = S.tri_hot[3 * slot], h1 = S.tri_hot[3 * slot + 1], h2 = S.tri_hot[3 * slot + 2];
-                        float t, u, v;
-                        if (triangle_tuv(mk(h0.x, h0.y, h0.z), mk(h0.w, h1.x, h1.y), mk(h1.z, h1.w, h2.x), lr, t, u, v) &&
-                            (!m_have || t < m_t || (t == m_t && slot < m_slot))) {
-                            m_have = true; m_t = t; m_u = u; m_v = v; m_slot = slot;
-                            improved = true;
-                        }
-                    }
-#endif
                     if (improved) {
                         atomicMin((unsigned long long*)&recs[4 * owner], make_key(m_t, m_slot));
                         // does this candidate already prove a shadow ray blocked (see rt_root)?
@@ -1181,16 +1161,34 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
                             recs[4 * owner + 3] = 1u;
                         }
                     }
+                }
+#ifdef RT_STATS
+                tm[7] += clock64() - tl0;
+#endif
+            }
+        }
+        // ---- one stack entry per walking lane that holds no leaf --------------------------------------------
+        if (running && pending_leaf == RT_REF_NONE && sp != base) {
+#ifdef RT_STATS
+            ++dbg_steps;
+#endif
+            --sp;
+            const uint32_t ref = stack[sp * RT_WAVE];
+            const float entry = __uint_as_float(stack_t[sp * RT_WAVE]);
+            const uint32_t pair_t = ((volatile uint32_t*)recs)[4 * owner + 1];     // closest hit any walker of the pair has
+            const uint32_t pair_done = ((volatile uint32_t*)recs)[4 * owner + 3];
+            float cut = RT_INF;                                      // boxes entered beyond this cannot matter
+            if (fast) {
+                float lim = (m_have && m_t < limit) ? m_t : limit;
+                if (pair_t != 0xFFFFFFFFu && __uint_as_float(pair_t) < lim) lim = __uint_as_float(pair_t);
+                cut = lim * RT_PRUNE_REL + prune_abs;
+            }
+            if (pair_done) sp = base;                                // another walker has proven the shadow
+            else if (!(entry > cut)) {
+                if (ref & RT_REF_LEAF_BIT) {
+                    if ((ref >> RT_REF_COUNT_SHIFT) & 7u) pending_leaf = ref;
                 } else {
-#ifdef RT_STATS
-                    const unsigned long long ti0 = clock64();
-#endif
                     const float4 n0 = S.nodes[4 * ref], n1 = S.nodes[4 * ref + 1], n2 = S.nodes[4 * ref + 2], n3 = S.nodes[4 * ref + 3];
-#ifdef RT_STATS
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    const unsigned long long ti1 = clock64();
-                    tm[2] += ti1 - ti0;          // node fetch
-#endif
                     float tl, tr;
                     bool hl = slab(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, lr.o, inv, tl);
                     bool hr = slab(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, lr.o, inv, tr);
@@ -1206,28 +1204,13 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
                     }
                     if (hl) { stack[sp * RT_WAVE] = rl; stack_t[sp * RT_WAVE] = __float_as_uint(tl); ++sp; }
                     if (hr) { stack[sp * RT_WAVE] = rr2; stack_t[sp * RT_WAVE] = __float_as_uint(tr); ++sp; }
-#ifdef RT_STATS
-                    tm[3] += clock64() - ti1;    // box tests and pushes
-#endif
                 }
             }
-            if (sp == base) {
-                running = false;                                     // settled in the next service phase
-                pending = true;
-#ifdef RT_STATS
-                dbg_steps = 0;
-#endif
-            }
         }
-#ifdef RT_STATS
-        {
-            const unsigned long long t_end = clock64();
-            leaf_lanes = __shfl(leaf_lanes, __ffsll((long long)run_mask) - 1 < 0 ? 0 : __ffsll((long long)run_mask) - 1);
-            if (run_mask) {
-                if (leaf_lanes) { tm[5] += 1; }
-            }
+        if (running && pending_leaf == RT_REF_NONE && sp == base) {
+            running = false;                                         // settled in the next service phase
+            pending = true;
         }
-#endif
     }
 #ifdef RT_STATS
     tm[0] = clock64() - t_begin;

@@ -19,8 +19,8 @@ for level in (0, 1, 2, 5, 9):
     tm = tm[tm[:, 1] > 0].astype(np.float64)
     tot = tm[:, 0].sum()
     print('level', level, 'waves', len(tm), 'cycles mean %.0f max %.0f rounds mean %.1f max %.0f lanes/round %.1f' % (tm[:, 0].mean(), tm[:, 0].max(), tm[:, 1].mean(), tm[:, 1].max(), tm[:, 8].sum() / tm[:, 1].sum()))
-    print('   share of wave time: ' + ' '.join('%s %.1f%%' % (names[k], 100 * tm[:, k].sum() / tot) for k in (9, 4, 2, 3, 6, 7)),
-          '| per round: ' + ' '.join('%s %.0f' % (names[k], tm[:, k].sum() / tm[:, 1].sum()) for k in (9, 4, 2, 3, 6, 7)), 'leaf rounds %.0f%%' % (100 * tm[:, 5].sum() / tm[:, 1].sum()))
+    print('   service %.1f%% of wave time; leaf rounds %.0f%% of rounds, %.1f lanes and %.0f cycles per leaf round (%.1f%% of wave time)' % (
+        100 * tm[:, 9].sum() / tot, 100 * tm[:, 5].sum() / tm[:, 1].sum(), tm[:, 6].sum() / max(tm[:, 5].sum(), 1), tm[:, 7].sum() / max(tm[:, 5].sum(), 1), 100 * tm[:, 7].sum() / tot))
     ts = np.zeros((8192, 8), dtype=np.uint64)
     L.rt_debug_setup_timing.argtypes = [C.c_void_p, C.c_size_t]
     L.rt_debug_setup_timing(ts.ctypes.data, ts.size)
