@@ -34,6 +34,21 @@
 #endif
 
 #define RT_BLOCK_THREADS 256
+// Block sizes of the list kernels.  Their grids are fixed (one list segment per block); 512-thread blocks were
+// measured to change nothing on the 1080p bunnies frame, so all stay at 256.
+#ifndef RT_SETUP_THREADS
+#define RT_SETUP_THREADS 256
+#endif
+#ifndef RT_ROOT_THREADS
+#define RT_ROOT_THREADS 256
+#endif
+#ifndef RT_SHADE_THREADS
+#define RT_SHADE_THREADS 256
+#endif
+#ifndef RT_PHONG_THREADS
+#define RT_PHONG_THREADS 256
+#endif
+#define RT_MAX_LIST_THREADS 512
 #define RT_WAVE 64
 
 namespace {
@@ -196,6 +211,12 @@ __device__ __forceinline__ bool slab(float lx, float ly, float lz, float hx, flo
 // (measured on the 1080p bunnies frame: 16/4 2.02 ms, 32/2 1.71 ms, 48/2 1.72 ms of BVH walk per frame).
 #ifndef RT_LEAF_BATCH
 #define RT_LEAF_BATCH 32
+#endif
+#ifndef RT_REFILL_IDLE
+#define RT_REFILL_IDLE 16          // idle lanes of a wave that make it fetch new pairs
+#endif
+#ifndef RT_SHARE_IDLE
+#define RT_SHARE_IDLE 16           // idle lanes that make a wave without input share its pending subtrees
 #endif
 #ifndef RT_LEAF_SHARE
 #define RT_LEAF_SHARE 2
@@ -565,7 +586,7 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_generate(const DFrame F) 
     __syncthreads();
     const uint32_t lane = threadIdx.x & (RT_WAVE - 1);
     const uint32_t gwave = (blockIdx.x * blockDim.x + threadIdx.x) / RT_WAVE;
-    const uint32_t n_waves = gridDim.x * (RT_BLOCK_THREADS / RT_WAVE);
+    const uint32_t n_waves = gridDim.x * (blockDim.x / RT_WAVE);
     for (uint32_t c = gwave; (unsigned long long)c * RT_WAVE < F.n_pixels; c += n_waves) {
         const uint32_t p = c * RT_WAVE + lane;
         uint32_t col = 0, row = 0;
@@ -601,7 +622,7 @@ extern "C" hipError_t rt_debug_setup_timing(unsigned long long* out, size_t n) {
 // enters within the distance that still matters.  Rays with a non-finite component are traced to the
 // end here, in the reference's exact order.
 // ======================================================================================================
-__global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_setup(const DScene S, const DFrame F, const uint32_t level) {
+__global__ void __launch_bounds__(RT_SETUP_THREADS) rt_setup(const DScene S, const DFrame F, const uint32_t level) {
     extern __shared__ uint32_t lds[];
     uint32_t* pre = lds;                       // n_seg + 1
     uint32_t* scratch = lds + F.n_seg + 1;     // blockDim.x
@@ -641,7 +662,7 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_setup(const DScene S, con
     const float4* rays = F.rays[p];
     const uint32_t lane = threadIdx.x & (RT_WAVE - 1);
     const uint32_t gwave = (blockIdx.x * blockDim.x + threadIdx.x) / RT_WAVE;
-    const uint32_t n_waves = gridDim.x * (RT_BLOCK_THREADS / RT_WAVE);
+    const uint32_t n_waves = gridDim.x * (blockDim.x / RT_WAVE);
 
     for (uint32_t c = gwave; (unsigned long long)c * RT_WAVE < n_rays; c += n_waves) {
         const uint32_t v = c * RT_WAVE + lane;
@@ -764,7 +785,7 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_setup_slow(const DScene S
     const float4* rays = F.rays[p];
     const uint32_t lane = threadIdx.x & (RT_WAVE - 1);
     const uint32_t gwave = (blockIdx.x * blockDim.x + threadIdx.x) / RT_WAVE;
-    const uint32_t n_waves = gridDim.x * (RT_BLOCK_THREADS / RT_WAVE);
+    const uint32_t n_waves = gridDim.x * (blockDim.x / RT_WAVE);
 
     for (uint32_t c = gwave; (unsigned long long)c * RT_WAVE < n_rays; c += n_waves) {
         const uint32_t v = c * RT_WAVE + lane;
@@ -863,7 +884,7 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_setup_slow(const DScene S
 // (the first iteration of intersect.rs:245-250).  Items that pass become 64-byte entries (see RT_FAT_FAST in
 // rt_device.h) the walk can start from with one fetch.
 // ======================================================================================================
-__global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_root(const DScene S, const DFrame F, const uint32_t level) {
+__global__ void __launch_bounds__(RT_ROOT_THREADS) rt_root(const DScene S, const DFrame F, const uint32_t level) {
     extern __shared__ uint32_t lds[];
     uint32_t* pre = lds;
     uint32_t* scratch = lds + F.n_seg + 1;
@@ -873,7 +894,7 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_root(const DScene S, cons
     const float4* rays = F.rays[level & 1];
     const uint32_t lane = threadIdx.x & (RT_WAVE - 1);
     const uint32_t gwave = (blockIdx.x * blockDim.x + threadIdx.x) / RT_WAVE;
-    const uint32_t n_waves = gridDim.x * (RT_BLOCK_THREADS / RT_WAVE);
+    const uint32_t n_waves = gridDim.x * (blockDim.x / RT_WAVE);
     for (uint32_t c = gwave; (unsigned long long)c * RT_WAVE < n_items; c += n_waves) {
         const uint32_t v = c * RT_WAVE + lane;
         bool pass = false;
@@ -962,7 +983,7 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
                      wave * (4 * RT_WAVE);
     uint32_t* donor_list = scratch + wave * RT_WAVE;               // free again once the prefix table is built
     const uint32_t gwave = (blockIdx.x * blockDim.x + threadIdx.x) / RT_WAVE;
-    const uint32_t n_waves = gridDim.x * (RT_BLOCK_THREADS / RT_WAVE);
+    const uint32_t n_waves = gridDim.x * (blockDim.x / RT_WAVE);
     const float4* rays = F.rays[level & 1];
 
     // Input is handed out in chunks of 64 pairs: every wave starts with the chunk of its own index, further ones
@@ -1003,12 +1024,12 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
         // of lanes that are still walking, so that one long walk does not keep 63 lanes (and the kernel) waiting
         bool can_give = false;
         unsigned long long give_mask = 0;
-        if (out_of_input && idle_mask != 0 && run_mask != 0) {
+        if (out_of_input && __popcll(idle_mask) >= RT_SHARE_IDLE && run_mask != 0) {
             can_give = running && fast && sp - base >= 2 && !(stack[base * RT_WAVE] & RT_REF_LEAF_BIT);
             give_mask = __ballot(can_give);
         }
         // ---- service: once a quarter of the wave is idle, nobody is walking, or there is something to share ---
-        if (run_mask == 0 || __popcll(idle_mask) >= 16 || give_mask != 0) {
+        if (run_mask == 0 || (!out_of_input && __popcll(idle_mask) >= RT_REFILL_IDLE) || give_mask != 0) {
 #ifdef RT_STATS
             serviced = true;
 #endif
@@ -1223,7 +1244,7 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
 // (raytracer.rs:65-135), except the Phong sum, which has to wait for its shadow rays (kernel D).
 // Shadow rays only record their verdict (raytracer.rs:171-187).
 // ======================================================================================================
-__global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_shade(const DScene S, const DFrame F, const uint32_t level) {
+__global__ void __launch_bounds__(RT_SHADE_THREADS) rt_shade(const DScene S, const DFrame F, const uint32_t level) {
     extern __shared__ uint32_t lds[];
     uint32_t* pre = lds;
     uint32_t* scratch = lds + F.n_seg + 1;
@@ -1239,7 +1260,7 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_shade(const DScene S, con
     float4* rays_out = F.rays[q];
     const uint32_t lane = threadIdx.x & (RT_WAVE - 1);
     const uint32_t gwave = (blockIdx.x * blockDim.x + threadIdx.x) / RT_WAVE;
-    const uint32_t n_waves = gridDim.x * (RT_BLOCK_THREADS / RT_WAVE);
+    const uint32_t n_waves = gridDim.x * (blockDim.x / RT_WAVE);
     uint32_t n_primary = 0, n_shadow = 0, n_reflected = 0, n_transmitted = 0;
 
     for (uint32_t c = gwave; (unsigned long long)c * RT_WAVE < n_rays; c += n_waves) {
@@ -1402,7 +1423,7 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_shade(const DScene S, con
 // Kernel D: the Phong sum of shade_phong / radiance (raytracer.rs:75-84, 137-153) for the hits of the
 // previous depth, now that their shadow rays have been traced.
 // ======================================================================================================
-__global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_phong(const DScene S, const DFrame F, const uint32_t level) {
+__global__ void __launch_bounds__(RT_PHONG_THREADS) rt_phong(const DScene S, const DFrame F, const uint32_t level) {
     extern __shared__ uint32_t lds[];
     uint32_t* pre = lds;
     uint32_t* scratch = lds + F.n_seg + 1;
@@ -1410,7 +1431,7 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_phong(const DScene S, con
     const uint32_t n_hits = build_prefix(F.hit_counts[q], F.n_seg, F.seg_hits, F.ovf_hits, pre, scratch);
     const uint32_t lane = threadIdx.x & (RT_WAVE - 1);
     const uint32_t gwave = (blockIdx.x * blockDim.x + threadIdx.x) / RT_WAVE;
-    const uint32_t n_waves = gridDim.x * (RT_BLOCK_THREADS / RT_WAVE);
+    const uint32_t n_waves = gridDim.x * (blockDim.x / RT_WAVE);
     for (uint32_t c = gwave; (unsigned long long)c * RT_WAVE < n_hits; c += n_waves) {
         const uint32_t v = c * RT_WAVE + lane;
         if (v >= n_hits) continue;
@@ -1511,13 +1532,13 @@ __global__ void rt_assemble(const uint8_t* gathered, uint8_t* frame, uint32_t wi
 
 // ---- launch wrappers (called from rt_api.hip) ----------------------------------------------------
 
-static size_t list_lds_bytes(uint32_t n_seg) { return (size_t)(n_seg + 1 + RT_BLOCK_THREADS) * sizeof(uint32_t); }
+static size_t list_lds_bytes(uint32_t n_seg) { return (size_t)(n_seg + 1 + RT_MAX_LIST_THREADS) * sizeof(uint32_t); }
 
 static size_t traverse_lds_bytes(uint32_t n_seg, uint32_t stack_entries) {
     // prefix table and scan scratch; two words per stack entry (child reference, box entry distance), one column
     // per lane; then, 16-byte aligned, one 16-byte pair record per lane
-    return list_lds_bytes(n_seg) + (size_t)(RT_BLOCK_THREADS / RT_WAVE) * 2 * stack_entries * RT_WAVE * sizeof(uint32_t) + 16 +
-           (size_t)RT_BLOCK_THREADS * 16;
+    return (size_t)(n_seg + 1 + RT_BLOCK_THREADS) * sizeof(uint32_t) +
+           (size_t)(RT_BLOCK_THREADS / RT_WAVE) * 2 * stack_entries * RT_WAVE * sizeof(uint32_t) + 16 + (size_t)RT_BLOCK_THREADS * 16;
 }
 
 // Resident blocks of the traversal kernel per compute unit (registers and the LDS stacks decide).
@@ -1544,13 +1565,13 @@ extern "C" hipError_t rt_launch_level(const DScene* S, const DFrame* F, uint32_t
     if (stop && level > (uint32_t)atoi(stop)) return hipSuccess;
 #endif
     if (marks) (void)hipEventRecord(marks[0], stream);
-    hipLaunchKernelGGL(rt_setup, dim3(blocks), dim3(RT_BLOCK_THREADS), lds + analytic_stage_words(*S) * sizeof(uint32_t), stream, *S,
+    hipLaunchKernelGGL(rt_setup, dim3(blocks), dim3(RT_SETUP_THREADS), lds + analytic_stage_words(*S) * sizeof(uint32_t), stream, *S,
                        *F, level);
     hipLaunchKernelGGL(rt_setup_slow, dim3(blocks), dim3(RT_BLOCK_THREADS), lds + analytic_stage_words(*S) * sizeof(uint32_t), stream,
                        *S, *F, level);
     if (marks) (void)hipEventRecord(marks[1], stream);
     if (S->n_instances > 0)
-        hipLaunchKernelGGL(rt_root, dim3(blocks), dim3(RT_BLOCK_THREADS), lds, stream, *S, *F, level);
+        hipLaunchKernelGGL(rt_root, dim3(blocks), dim3(RT_ROOT_THREADS), lds, stream, *S, *F, level);
     if (marks) (void)hipEventRecord(marks[2], stream);
     if (S->n_instances > 0)
         hipLaunchKernelGGL(rt_traverse, dim3(traverse_blocks), dim3(RT_BLOCK_THREADS), traverse_lds_bytes(F->n_seg, S->stack_entries),
@@ -1559,10 +1580,10 @@ extern "C" hipError_t rt_launch_level(const DScene* S, const DFrame* F, uint32_t
     if (stop && level == (uint32_t)atoi(stop)) return hipGetLastError();
 #endif
     if (marks) (void)hipEventRecord(marks[3], stream);
-    hipLaunchKernelGGL(rt_shade, dim3(blocks), dim3(RT_BLOCK_THREADS), lds, stream, *S, *F, level);
+    hipLaunchKernelGGL(rt_shade, dim3(blocks), dim3(RT_SHADE_THREADS), lds, stream, *S, *F, level);
     if (marks) (void)hipEventRecord(marks[4], stream);
     if (level > 0 && S->n_lights > 0)
-        hipLaunchKernelGGL(rt_phong, dim3(blocks), dim3(RT_BLOCK_THREADS), lds, stream, *S, *F, level);
+        hipLaunchKernelGGL(rt_phong, dim3(blocks), dim3(RT_PHONG_THREADS), lds, stream, *S, *F, level);
     if (marks) (void)hipEventRecord(marks[5], stream);
     return hipGetLastError();
 }

@@ -11,5 +11,7 @@ ts = []
 dev.set_kernel_timing(True)
 for _ in range(6):
     dev.render(max_depth=10)
-    ts.append((dev.last_trace_ms(), dev.last_kernel_ms()['rt_traverse'][0]))
-print(sys.argv[1:] , 'trace %.3f traverse %.3f' % min(ts))
+    k = dev.last_kernel_ms()
+    ts.append((dev.last_trace_ms(),) + tuple(k[n][0] for n in dev.LEVEL_KERNELS))
+b = min(ts)
+print(sys.argv[1:], 'trace %.3f' % b[0], ' '.join('%s %.3f' % (n[3:], v) for n, v in zip(dev.LEVEL_KERNELS, b[1:])))
