@@ -69,6 +69,53 @@ def test_reference_scenes(scenes_dir, model_dir, name, width, height, depth):
     assert_parity(got, want)
 
 
+def test_headline_workload_at_full_size(scenes_dir, tmp_path_factory):
+    """The benchmark's own configuration: reflective_bunnies at 1920x1080, depth 10, the 81 920-triangle
+    stand-in bunny - every pixel against the oracle."""
+    from rust_raytracer_amd import meshes
+    full_models = meshes.ensure_model_dir(str(tmp_path_factory.mktemp("full_models")), names=["bunny.obj"])
+    s = load(scenes_dir, full_models, "reflective_bunnies", 1920, 1080)
+    got, want = render_both(s)
+    exact, within = assert_parity(got, want)
+    assert got["counters"][0] == 17899018            # the ray count bench.py divides by
+    assert exact >= 0.9999
+
+
+@pytest.mark.parametrize("grid,n_meshes,level,width,height", [(4, 4, 3, 480, 270), (7, 5, 2, 320, 180)])
+def test_instance_grid(tmp_path_factory, grid, n_meshes, level, width, height):
+    """Many instances over several distinct meshes, arbitrary rotations and non-uniform scales, two lights,
+    reflective and matte cells (the synthetic many-mesh configuration at a small size)."""
+    from rust_raytracer_amd import synthetic
+    d = str(tmp_path_factory.mktemp("grid_models"))
+    text = synthetic.instance_grid_scene(d, grid, n_meshes, level, width, height)
+    s = orc.OracleScene.from_text(text, d)
+    got, want = render_both(s)
+    assert_parity(got, want)
+    assert (got["prim_id"] >> 30 == abi.RT_PRIM_MESH_TRIANGLE).sum() > width * height // 20
+
+
+def test_orbit_views(scenes_dir, model_dir):
+    """One uploaded scene, eight camera poses on a circle around it (the batch-of-views configuration at a
+    small size): only the camera matrix crosses to the device between frames."""
+    from rust_raytracer_amd import synthetic
+    s = load(scenes_dir, model_dir, "reflective_bunnies", 320, 180)
+    host = native.HostScene.load(os.path.join(scenes_dir, "reflective_bunnies.json"), model_dir)
+    host.resize_screen(320, 180)
+    dev = native.DeviceScene(s.desc(), 0)
+    try:
+        for position, orientation in synthetic.orbit_poses(8, centre=(0.0, 0.0, -6.0)):
+            host.set_camera_pose(position, orientation)
+            m, w, h = host.camera()
+            dev.set_camera(m, w, h)
+            s.set_camera_matrix(m, w, h)
+            got = dev.render(aux=True)
+            want = s.render()
+            assert_parity(got, want)
+    finally:
+        dev.close()
+        host.close()
+
+
 @pytest.mark.parametrize("depth", [1, 2, 3])
 def test_depth_limit(scenes_dir, model_dir, depth):
     # raytracer.rs:66: a child requested at depth == max_depth is not traced, its parent takes the background
