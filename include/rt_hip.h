@@ -200,11 +200,17 @@ enum { RT_FORMAT_RGB8 = 0, RT_FORMAT_RGBA8 = 1 };
  * row interlacing of web_app/wasm/src/renderer.rs:68-76, in two dimensions. */
 #define RT_TILE_DIM 32
 
+/* What a pixel shows: Raytracer::raytrace (raytracer.rs:17-19) or Raytracer::depth_map (raytracer.rs:21-28,
+ * brightness 2^-t * 1.5 of the primary hit, the background where there is none). */
+enum { RT_MODE_RAYTRACE = 0, RT_MODE_DEPTH_MAP = 1 };
+
 typedef struct RtRenderParams {
     uint32_t max_depth;       /* MAX_RAY_RECURSION_DEPTH, raytracer.rs:9; 0 means RT_DEFAULT_MAX_DEPTH */
     uint32_t output_format;   /* RT_FORMAT_* ; RGBA8 sets alpha = 255 as web_app/wasm/src/color.rs:10-21 */
     uint32_t shard_index;     /* which tiles to render: see RT_TILE_DIM */
     uint32_t shard_count;     /* 0 or 1 = the whole frame */
+    uint32_t mode;            /* RT_MODE_* */
+    uint32_t reserved;        /* must be 0 */
     void* stream;             /* hipStream_t to enqueue on; NULL = the handle's own stream */
 } RtRenderParams;
 

@@ -146,6 +146,17 @@ class OracleScene:
             raise RuntimeError("oracle: " + lib().orc_last_error().decode())
         return {"rgb": rgb, "prim_id": prim, "instance_id": inst, "flags": flags, "counters": ctr}
 
+    def render_depth_map(self, threads: int = 0, channels: int = 3):
+        """Raytracer::depth_map for every pixel (raytracer.rs:21-28): dict(rgb, counters)."""
+        m, w, h = self.camera()
+        rgb = np.zeros((h, w, channels), dtype=np.uint8)
+        counters = np.zeros(abi.RT_N_COUNTERS, dtype=np.uint64)
+        L = lib()
+        L.orc_render_depth_map.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        if L.orc_render_depth_map(self._h, threads or (os.cpu_count() or 1), channels, rgb.ctypes.data, counters.ctypes.data) != 0:
+            raise RuntimeError(L.orc_last_error().decode())
+        return {"rgb": rgb, "counters": counters}
+
     def trace_pixel(self, x: float, y: float, max_depth: int = 10):
         col = (C.c_float * 3)()
         ids = (C.c_uint32 * 2)()

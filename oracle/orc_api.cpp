@@ -108,6 +108,16 @@ int orc_render(void* h, uint32_t max_depth, int threads, uint32_t row_begin, uin
     }
 }
 
+int orc_render_depth_map(void* h, int threads, int channels, uint8_t* rgb, uint64_t* counters) {
+    try {
+        render_depth_map(*static_cast<Scene*>(h), threads, channels, rgb, counters);
+        return 0;
+    } catch (const std::exception& e) {
+        g_error = e.what();
+        return -1;
+    }
+}
+
 // Unquantised colour of one pixel; (x, y) in the reference's screen coordinates (y up).
 int orc_trace_pixel(void* h, float x, float y, uint32_t max_depth, float color[3], uint32_t ids[2], uint8_t* flags) {
     try {

@@ -478,6 +478,45 @@ PixelResult trace_pixel(const Scene& s, float x, float y, uint32_t max_depth, Co
     return r;
 }
 
+// Raytracer::depth_map, raytracer.rs:7-8, 21-28: brightness 2^-t * 1.5 of the primary hit; a miss is None, for
+// which the pixel loop substitutes the background exactly as it does for raytrace (main.rs:58-61).
+Vec3 depth_map_pixel(const Scene& s, float x, float y, Counters* ctr) {
+    Tracer tr{s, 1, ctr};
+    Ray ray = generate_primary_ray(s, x, y);
+    Hitpoint h;
+    if (!tr.count_intersect(ray, &h, RT_CTR_PRIMARY)) return tr.trace_background(ray);
+    float brightness = std::pow(2.0f, -h.t) * 1.5f;
+    return {brightness, brightness, brightness};
+}
+
+void render_depth_map(const Scene& s, int threads, int channels, uint8_t* rgb, uint64_t counters[RT_N_COUNTERS]) {
+    uint32_t W = s.camera.width, H = s.camera.height;
+    if (threads < 1) threads = 1;
+    std::atomic<uint32_t> next_row{0};
+    std::vector<Counters> per_thread(threads);
+    auto worker = [&](int tid) {
+        for (;;) {
+            uint32_t row = next_row.fetch_add(1);
+            if (row >= H) break;
+            for (uint32_t x = 0; x < W; ++x) {
+                size_t idx = (size_t)row * W + x;
+                quantize(depth_map_pixel(s, (float)x, (float)(H - 1 - row), &per_thread[tid]), rgb + idx * channels);
+                if (channels == 4) rgb[idx * 4 + 3] = 255;
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; ++t) pool.emplace_back(worker, t);
+    worker(0);
+    for (auto& th : pool) th.join();
+    if (counters)
+        for (int k = 0; k < RT_N_COUNTERS; ++k) {
+            uint64_t sum = 0;
+            for (auto& c : per_thread) sum += c.c[k];
+            counters[k] = sum;
+        }
+}
+
 // native_app/src/main.rs:46-66 + canvas.rs:35-46 (canvas row r shows screen y = H-1-r)
 void render_frame(const Scene& s, uint32_t max_depth, int threads, uint32_t row_begin, uint32_t row_end, int channels,
                   uint8_t* rgb, uint32_t* prim_id, uint32_t* instance_id, uint8_t* flags,

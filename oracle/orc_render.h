@@ -27,6 +27,7 @@ bool intersect_plane(const RtPlane& p, const Ray& ray, Hitpoint* out);
 bool intersect_triangle(const RtTriangle& t, const Ray& ray, Hitpoint* out);
 bool intersect_aabb(const float bmin[3], const float bmax[3], const Ray& ray);
 // scene.rs:120-140
+void render_depth_map(const Scene& s, int threads, int channels, uint8_t* rgb, uint64_t counters[RT_N_COUNTERS]);
 bool intersect_scene(const Scene& s, const Ray& ray, Hitpoint* out, Counters* ctr);
 
 struct PixelResult {

@@ -91,7 +91,10 @@ class RtAux(C.Structure):
 
 class RtRenderParams(C.Structure):
     _fields_ = [("max_depth", u32), ("output_format", u32), ("shard_index", u32), ("shard_count", u32),
-                ("stream", C.c_void_p)]
+                ("mode", u32), ("reserved", u32), ("stream", C.c_void_p)]
+
+
+RT_MODE_RAYTRACE, RT_MODE_DEPTH_MAP = 0, 1
 
 
 def desc_arrays(desc: RtSceneDesc) -> dict:

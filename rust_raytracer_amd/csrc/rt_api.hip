@@ -531,12 +531,14 @@ static int enqueue_frame(RtScene* s, const RtRenderParams* p, bool sharded, bool
     uint32_t max_depth = p->max_depth ? p->max_depth : RT_DEFAULT_MAX_DEPTH;
     if (max_depth > RT_MAX_DEPTH_LIMIT) return fail(RT_ERR_INVALID_ARGUMENT, "max_depth %u exceeds the limit of %d", max_depth, RT_MAX_DEPTH_LIMIT);
     if (s->d.n_lights > 255) return fail(RT_ERR_INVALID_ARGUMENT, "%u lights; at most 255 are supported", s->d.n_lights);
+    if (p->mode > RT_MODE_DEPTH_MAP || p->reserved != 0) return fail(RT_ERR_INVALID_ARGUMENT, "unknown mode %u / reserved %u", p->mode, p->reserved);
     // a list of an earlier frame did not fit: that frame was invalid, this one gets longer lists
     if (*s->h_overflow) { *s->h_overflow = 0; ++s->capacity_shift; }
     if ((rc = ensure_frame(s, g, max_depth, aux))) return rc;
     hipStream_t stream = p->stream ? (hipStream_t)p->stream : s->own_stream;
     s->last_stream = stream;
     DFrame f = s->f;
+    f.mode = p->mode;
     if (!aux) f.aux_flags = f.aux_prim = f.aux_inst = nullptr;
     HIP_TRY(hipEventRecord(s->ev_start, stream));
     HIP_TRY(hipMemsetAsync(f.acc, 0, s->pixel_clear_bytes, stream));                              // colour sums + poison words
@@ -544,7 +546,8 @@ static int enqueue_frame(RtScene* s, const RtRenderParams* p, bool sharded, bool
     if (aux) HIP_TRY(hipMemsetAsync(f.aux_flags, 0, (size_t)g.n_pixels * sizeof(unsigned int), stream));
     HIP_TRY(hipEventRecord(s->ev_trace_start, stream));
     HIP_TRY(rt_launch_generate(&f, s->list_blocks, stream));
-    const uint32_t last = s->d.n_lights > 0 ? max_depth : max_depth - 1;
+    // a depth map only looks at the primary hits
+    const uint32_t last = p->mode == RT_MODE_DEPTH_MAP ? 0 : (s->d.n_lights > 0 ? max_depth : max_depth - 1);
     s->marked_levels = 0;
     if (s->kernel_timing) {
         while (s->marks.size() < (RT_N_LEVEL_KERNELS + 1) * (size_t)(last + 1)) {

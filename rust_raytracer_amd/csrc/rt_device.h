@@ -115,6 +115,7 @@ struct DFrame {
     uint32_t n_local_tiles;          // tiles this shard owns (rounded up so every shard has the same number)
     uint32_t n_pixels;               // n_local_tiles * RT_TILE_DIM^2
     uint32_t max_depth;
+    uint32_t mode;                   // RT_MODE_*
     uint32_t n_seg;                  // producer blocks + 1 (the last segment is the shared overflow segment)
     uint32_t seg_rays, ovf_rays;     // capacity of a block's ray segment / of the overflow segment
     uint32_t seg_items, ovf_items;   // (ray, instance) pairs that pass the culling box

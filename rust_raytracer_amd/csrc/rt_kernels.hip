@@ -1302,6 +1302,10 @@ __global__ void __launch_bounds__(RT_SHADE_THREADS) rt_shade(const DScene S, con
             if (!have) {
                 // raytrace returned None: the caller substitutes the background (main.rs:58-61, raytracer.rs:92,110,112)
                 add_color(F, pixel, background(S, cur.ray.d) * cur.throughput);
+            } else if (F.mode == RT_MODE_DEPTH_MAP) {
+                // Raytracer::depth_map, raytracer.rs:21-28 (DEPTH_MAP_EXP_BASE 2, DEPTH_MAP_BRIGHTNESS_SCALE 1.5)
+                const float brightness = powf(2.0f, -best_t) * 1.5f;
+                add_color(F, pixel, mk(brightness, brightness, brightness) * cur.throughput);
             } else {
                 Closest cl;
                 cl.have = true; cl.t = best_t; cl.inst = RT_INSTANCE_NONE; cl.slot = 0; cl.tl = cl.u = cl.v = 0.0f;

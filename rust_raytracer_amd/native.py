@@ -129,14 +129,15 @@ class DeviceScene:
         self.width, self.height = width, height
 
     @staticmethod
-    def _params(max_depth=10, fmt=abi.RT_FORMAT_RGB8, shard_index=0, shard_count=1, stream=None):
-        return abi.RtRenderParams(max_depth, fmt, shard_index, shard_count, stream)
+    def _params(max_depth=10, fmt=abi.RT_FORMAT_RGB8, shard_index=0, shard_count=1, stream=None, mode=abi.RT_MODE_RAYTRACE):
+        return abi.RtRenderParams(max_depth, fmt, shard_index, shard_count, mode, 0, stream)
 
-    def render(self, max_depth: int = 10, channels: int = 3, aux: bool = False):
+    def render(self, max_depth: int = 10, channels: int = 3, aux: bool = False, depth_map: bool = False):
         """Whole frame to host memory: dict(rgb[H,W,channels], counters, and with aux prim_id / instance_id / flags)."""
         h, w = self.height, self.width
         rgb = np.zeros((h, w, channels), dtype=np.uint8)
-        p = self._params(max_depth, abi.RT_FORMAT_RGBA8 if channels == 4 else abi.RT_FORMAT_RGB8)
+        p = self._params(max_depth, abi.RT_FORMAT_RGBA8 if channels == 4 else abi.RT_FORMAT_RGB8,
+                         mode=abi.RT_MODE_DEPTH_MAP if depth_map else abi.RT_MODE_RAYTRACE)
         a = abi.RtAux()
         out = {"rgb": rgb}
         if aux:

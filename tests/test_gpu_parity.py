@@ -116,6 +116,25 @@ def test_orbit_views(scenes_dir, model_dir):
         host.close()
 
 
+@pytest.mark.parametrize("name", ["cornell_box", "reflective_bunnies"])
+def test_depth_map_mode(scenes_dir, model_dir, name):
+    """Raytracer::depth_map (raytracer.rs:21-28) instead of raytrace: 2^-t * 1.5 of the primary hit."""
+    s = load(scenes_dir, model_dir, name, 320, 180)
+    m, w, h = s.camera()
+    dev = native.DeviceScene(s.desc(), 0)
+    try:
+        dev.set_camera(m, w, h)
+        got = dev.render(depth_map=True)
+    finally:
+        dev.close()
+    want = s.render_depth_map()
+    assert got["counters"][:5].tolist() == [w * h, w * h, 0, 0, 0]
+    assert want["counters"][0] == w * h
+    diff = np.abs(got["rgb"].astype(int) - want["rgb"].astype(int)).max(axis=2)
+    assert (diff <= 1).mean() >= 0.999 and diff.max() <= 1        # powf is the only inexact step
+    assert len(np.unique(got["rgb"])) > 5                           # a real gradient, not a constant image
+
+
 @pytest.mark.parametrize("depth", [1, 2, 3])
 def test_depth_limit(scenes_dir, model_dir, depth):
     # raytracer.rs:66: a child requested at depth == max_depth is not traced, its parent takes the background

@@ -102,3 +102,28 @@ def test_matrix_inverse_roundtrip():
         prod = orc.mat_mul(m, inv).reshape(4, 4)
         assert np.allclose(prod, np.eye(4), atol=2e-3)
     assert orc.mat_inverse(np.zeros(16)).tolist() == [0.0] * 16      # glm::inverse of a singular matrix
+
+
+def test_depth_map_of_a_sphere():
+    """Raytracer::depth_map (raytracer.rs:21-28): brightness = 2^-t * 1.5, clamped and quantised like any colour;
+    a miss shows the background.  Unit-free check on one sphere seen head-on through an orthogonal pixel ray."""
+    import json
+    scene = {
+        "camera": {"position": {"x": 0, "y": 0, "z": 0}, "orientation_degrees": {"x": 0, "y": 0, "z": 0},
+                   "screen_dimensions": [65, 65], "y_fov_degrees": 40, "z_near": 0.1, "z_far": 25,
+                   "use_perspective": True, "ortho_world_height": 10},
+        "background": {"SolidColor": {"r": 0, "g": 0, "b": 1}},
+        "lights": [], "planes": [], "triangles": [],
+        "materials": [{"name": "m", "emissive": {"r": 0, "g": 0, "b": 0}, "ambient": {"r": 0, "g": 0, "b": 0},
+                       "diffuse": {"r": 0, "g": 0, "b": 0}, "specular": {"r": 0, "g": 0, "b": 0}, "shininess": 1,
+                       "material_type": "Phong"}],
+        "spheres": [{"center": {"x": 0, "y": 0, "z": -4}, "radius": 1, "material": "m"}],
+    }
+    s = orc.OracleScene.from_text(json.dumps(scene))
+    out = s.render_depth_map(threads=1)["rgb"]
+    # the centre pixel's ray starts on the near plane (z = -0.1) and meets the sphere at z = -3: t = 2.9
+    centre = out[32, 32].astype(int)
+    expect = int(min(1.0, 2.0 ** -2.9 * 1.5) * 255)
+    assert abs(centre[0] - expect) <= 1 and centre[0] == centre[1] == centre[2]
+    assert out[0, 0].tolist() == [0, 0, 255]                     # a corner ray misses: background
+    assert out[32, 32, 0] > out[32, 20, 0] > 0                   # farther points of the sphere are darker
