@@ -69,6 +69,11 @@ int rt_host_scene_add_mesh(RtHostScene* scene, const char* name, const char* obj
 
 void rt_host_scene_destroy(RtHostScene* scene);
 
+/* Replaces `impl WritePng for Canvas` (native_app/src/write_png.rs:8-30): an 8-bit PNG of a canvas as rt_render
+ * fills it (row 0 = top), colour type RGB for channels == 3 (what the reference writes) or RGBA for 4.  The
+ * image data is stored uncompressed (valid deflate "stored" blocks): any PNG reader decodes the same pixels. */
+int rt_host_write_png(const char* path, const uint8_t* pixels, uint32_t width, uint32_t height, uint32_t channels);
+
 #ifdef __cplusplus
 }
 #endif

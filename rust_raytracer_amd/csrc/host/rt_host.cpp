@@ -9,6 +9,7 @@
 // are merged instead of re-scanned - min/max are exact, so the merge order does not matter).
 //
 // Compiled with -ffp-contract=off: float arithmetic below is plain IEEE binary32.
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -860,3 +861,79 @@ int rt_host_scene_add_mesh(RtHostScene* s, const char* name, const char* obj_dat
 void rt_host_scene_destroy(RtHostScene* s) { delete s; }
 
 }  // extern "C"
+
+
+// ---- PNG output (native_app/src/write_png.rs) -------------------------------------------------------
+namespace {
+struct Crc32 {
+    uint32_t table[256];
+    Crc32() {
+        for (uint32_t n = 0; n < 256; ++n) {
+            uint32_t c = n;
+            for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            table[n] = c;
+        }
+    }
+    uint32_t run(uint32_t crc, const uint8_t* p, size_t n) const {
+        for (size_t i = 0; i < n; ++i) crc = table[(crc ^ p[i]) & 0xFFu] ^ (crc >> 8);
+        return crc;
+    }
+};
+
+void put_u32(std::vector<uint8_t>& v, uint32_t x) {
+    v.push_back((uint8_t)(x >> 24)); v.push_back((uint8_t)(x >> 16)); v.push_back((uint8_t)(x >> 8)); v.push_back((uint8_t)x);
+}
+
+bool write_chunk(FILE* f, const Crc32& crc, const char type[4], const std::vector<uint8_t>& data) {
+    std::vector<uint8_t> head;
+    put_u32(head, (uint32_t)data.size());
+    head.insert(head.end(), type, type + 4);
+    uint32_t c = crc.run(0xFFFFFFFFu, head.data() + 4, 4);
+    c = crc.run(c, data.data(), data.size()) ^ 0xFFFFFFFFu;
+    std::vector<uint8_t> tail;
+    put_u32(tail, c);
+    return fwrite(head.data(), 1, head.size(), f) == head.size() &&
+           (data.empty() || fwrite(data.data(), 1, data.size(), f) == data.size()) && fwrite(tail.data(), 1, 4, f) == 4;
+}
+}  // namespace
+
+extern "C" int rt_host_write_png(const char* path, const uint8_t* pixels, uint32_t width, uint32_t height, uint32_t channels) {
+    if (!path || !pixels) return fail(RT_ERR_INVALID_ARGUMENT, "rt_host_write_png: null argument");
+    if (width == 0 || height == 0 || (channels != 3 && channels != 4))
+        return fail(RT_ERR_INVALID_ARGUMENT, "rt_host_write_png: %ux%u with %u channels", width, height, channels);
+    const size_t row = (size_t)width * channels;
+    // filtered scanlines: filter type 0 (None) in front of every row
+    std::vector<uint8_t> raw;
+    raw.reserve((row + 1) * height);
+    for (uint32_t y = 0; y < height; ++y) {
+        raw.push_back(0);
+        raw.insert(raw.end(), pixels + y * row, pixels + (y + 1) * row);
+    }
+    // zlib stream of stored blocks
+    std::vector<uint8_t> z;
+    z.reserve(raw.size() + raw.size() / 65535 * 5 + 16);
+    z.push_back(0x78); z.push_back(0x01);
+    uint32_t a = 1, b = 0;
+    for (size_t at = 0; at < raw.size();) {
+        const size_t n = std::min<size_t>(65535, raw.size() - at);
+        z.push_back(at + n == raw.size() ? 1 : 0);
+        z.push_back((uint8_t)(n & 0xFF)); z.push_back((uint8_t)(n >> 8));
+        z.push_back((uint8_t)(~n & 0xFF)); z.push_back((uint8_t)((~n >> 8) & 0xFF));
+        z.insert(z.end(), raw.begin() + at, raw.begin() + at + n);
+        for (size_t i = at; i < at + n; ++i) { a = (a + raw[i]) % 65521u; b = (b + a) % 65521u; }
+        at += n;
+    }
+    put_u32(z, (b << 16) | a);
+    FILE* f = fopen(path, "wb");
+    if (!f) return fail(RT_ERR_IO, "cannot create %s", path);
+    static const Crc32 crc;
+    static const uint8_t signature[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    std::vector<uint8_t> ihdr;
+    put_u32(ihdr, width); put_u32(ihdr, height);
+    ihdr.push_back(8); ihdr.push_back(channels == 4 ? 6 : 2); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
+    bool ok = fwrite(signature, 1, 8, f) == 8 && write_chunk(f, crc, "IHDR", ihdr) && write_chunk(f, crc, "IDAT", z) &&
+              write_chunk(f, crc, "IEND", std::vector<uint8_t>());
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) return fail(RT_ERR_IO, "writing %s failed", path);
+    return RT_OK;
+}

@@ -21,7 +21,7 @@ EXPORTS = ["rt_scene_create", "rt_scene_set_camera", "rt_render", "rt_render_dev
 HOST_EXPORTS = ["rt_host_scene_parse", "rt_host_scene_load", "rt_host_scene_desc", "rt_host_scene_camera",
                 "rt_host_scene_resize_screen", "rt_host_scene_turn_camera", "rt_host_scene_set_camera_pose",
                 "rt_host_scene_get_camera_pose", "rt_host_scene_find_material", "rt_host_scene_find_mesh",
-                "rt_host_scene_add_instance", "rt_host_scene_add_mesh", "rt_host_scene_destroy"]
+                "rt_host_scene_add_instance", "rt_host_scene_add_mesh", "rt_host_scene_destroy", "rt_host_write_png"]
 
 # RtMeshLoadFn of include/rt_host.h
 RELEASE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t)
@@ -203,6 +203,15 @@ class DeviceScene:
         n = C.c_uint32()
         check(lib().rt_debug_last_spilled(self._h, C.byref(n)))
         return int(n.value)
+
+
+def write_png(path: str, pixels: np.ndarray):
+    """native_app's `canvas.write_png(path)` (write_png.rs:8-30) for an (H, W, 3 or 4) uint8 canvas."""
+    h, w, c = pixels.shape
+    data = np.ascontiguousarray(pixels, dtype=np.uint8)
+    L = lib()
+    L.rt_host_write_png.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
+    check(L.rt_host_write_png(path.encode(), data.ctypes.data, w, h, c))
 
 
 def _f3(v):

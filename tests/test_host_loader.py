@@ -117,3 +117,18 @@ def test_render_without_gpu_fails_loudly(scenes_dir):
     with pytest.raises(native.RtError) as e:
         native.DeviceScene(scene.desc(), 0)
     assert e.value.code in (abi.RT_ERR_NO_DEVICE, abi.RT_ERR_DEVICE)
+
+
+def test_write_png_roundtrip(tmp_path):
+    """rt_host_write_png (write_png.rs:8-30): any PNG reader gets the canvas back, RGB and RGBA, also across the
+    65 535-byte limit of a stored deflate block."""
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    for shape in [(7, 5, 3), (90, 300, 3), (33, 65, 4)]:
+        img = rng.integers(0, 256, size=shape, dtype=np.uint8)
+        path = str(tmp_path / ("c%d_%d.png" % (shape[2], shape[0])))
+        native.write_png(path, img)
+        back = np.asarray(Image.open(path))
+        assert back.shape == shape and np.array_equal(back, img)
+    with pytest.raises(native.RtError):
+        native.write_png(str(tmp_path / "no_such_dir" / "x.png"), np.zeros((2, 2, 3), dtype=np.uint8))
