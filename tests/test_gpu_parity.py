@@ -221,3 +221,28 @@ def test_tile_shards_assemble_to_the_same_frame(scenes_dir, model_dir, shards):
         assert np.array_equal(full.cpu().numpy().reshape(h, w, 3), whole)
     finally:
         dev.close()
+
+
+def test_kernel_timing_mode(scenes_dir, model_dir):
+    """rt_set_kernel_timing / rt_last_kernel_ms: per-kernel HIP-event times of one frame, launch counts per depth,
+    and no effect on the image."""
+    s = load(scenes_dir, model_dir, "reflective_bunnies", 320, 180)
+    m, w, h = s.camera()
+    dev = native.DeviceScene(s.desc(), 0)
+    try:
+        dev.set_camera(m, w, h)
+        plain = dev.render(max_depth=4)["rgb"]
+        with pytest.raises(native.RtError):
+            dev.last_kernel_ms()                    # the last frame carried no marks
+        dev.set_kernel_timing(True)
+        timed = dev.render(max_depth=4)["rgb"]
+        k = dev.last_kernel_ms()
+        trace = dev.last_trace_ms()
+        dev.set_kernel_timing(False)
+    finally:
+        dev.close()
+    assert np.array_equal(plain, timed)
+    # depths 0..4 (the last one only holds shadow rays); the Phong sum starts at depth 1
+    assert {n: c for n, (ms, c) in k.items()} == {"rt_setup": 5, "rt_root": 5, "rt_traverse": 5, "rt_shade": 5, "rt_phong": 4}
+    assert all(ms > 0.0 for ms, c in k.values())
+    assert sum(ms for ms, c in k.values()) <= trace * 1.05
