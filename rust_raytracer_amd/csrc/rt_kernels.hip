@@ -999,6 +999,12 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
     bool pending = false;           // walk finished, its part in the pair's result not yet settled
     uint32_t item = 0, gi = 0, ii = 0, sp = 0, base = 0, owner = lane;
     uint32_t pending_leaf = RT_REF_NONE;                            // a leaf this lane has reached and not yet tested
+    // The entry the lane looks at next is already off the stack: its reference, its box entry distance and, for
+    // an inner node, the node itself, requested at the end of the previous step so that the fetch overlaps
+    // whatever the wave does in between.
+    uint32_t cur_ref = RT_REF_NONE;
+    float cur_t = 0.0f;
+    float4 nd0 = make_float4(0, 0, 0, 0), nd1 = nd0, nd2 = nd0, nd3 = nd0;
     Ray lr; lr.o = lr.d = mk(0, 0, 0);
     V3 inv = mk(0, 0, 0);
     bool fast = false;
@@ -1025,7 +1031,8 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
         bool can_give = false;
         unsigned long long give_mask = 0;
         if (out_of_input && __popcll(idle_mask) >= RT_SHARE_IDLE && run_mask != 0) {
-            can_give = running && fast && sp - base >= 2 && !(stack[base * RT_WAVE] & RT_REF_LEAF_BIT);
+            can_give = running && fast && sp - base >= 1 && (sp - base >= 2 || cur_ref != RT_REF_NONE || pending_leaf != RT_REF_NONE) &&
+                       !(stack[base * RT_WAVE] & RT_REF_LEAF_BIT);
             give_mask = __ballot(can_give);
         }
         // ---- service: once a quarter of the wave is idle, nobody is walking, or there is something to share ---
@@ -1090,9 +1097,12 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
                     fast = (__float_as_uint(q3.y) & RT_FAT_FAST) != 0;
                     item = __float_as_uint(q3.z);
                     m_have = false; m_t = 0.0f; m_u = 0.0f; m_v = 0.0f; m_slot = 0;
-                    stack[0] = __float_as_uint(q2.w);
-                    stack_t[0] = __float_as_uint(q0.w);
-                    sp = 1; base = 0;
+                    cur_ref = __float_as_uint(q2.w);
+                    cur_t = q0.w;
+                    if (!(cur_ref & RT_REF_LEAF_BIT)) {
+                        nd0 = S.nodes[4 * cur_ref]; nd1 = S.nodes[4 * cur_ref + 1]; nd2 = S.nodes[4 * cur_ref + 2]; nd3 = S.nodes[4 * cur_ref + 3];
+                    }
+                    sp = 0; base = 0;
                     owner = lane;
                     recs[4 * lane] = 0xFFFFFFFFu; recs[4 * lane + 1] = 0xFFFFFFFFu;
                     recs[4 * lane + 2] = 1u; recs[4 * lane + 3] = 0u;
@@ -1127,9 +1137,10 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
                     item = s_item; gi = s_gi; ii = s_ii; owner = s_owner;
                     fast = true;
                     m_have = false; m_t = 0.0f; m_u = 0.0f; m_v = 0.0f; m_slot = 0;
-                    stack[0] = wave_stack[s_base * RT_WAVE + src];
-                    stack_t[0] = wave_stack[(S.stack_entries + s_base) * RT_WAVE + src];
-                    sp = 1; base = 0;
+                    cur_ref = wave_stack[s_base * RT_WAVE + src];           // an inner node: leaves are not given away
+                    cur_t = __uint_as_float(wave_stack[(S.stack_entries + s_base) * RT_WAVE + src]);
+                    nd0 = S.nodes[4 * cur_ref]; nd1 = S.nodes[4 * cur_ref + 1]; nd2 = S.nodes[4 * cur_ref + 2]; nd3 = S.nodes[4 * cur_ref + 3];
+                    sp = 0; base = 0;
                     running = true;
                 }
                 if (giving) ++base;
@@ -1179,6 +1190,7 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
                         // does this candidate already prove a shadow ray blocked (see rt_root)?
                         if (m_t * inv_dn < shadow_thr) {
                             sp = base;
+                            cur_ref = RT_REF_NONE;
                             recs[4 * owner + 3] = 1u;
                         }
                     }
@@ -1188,14 +1200,11 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
 #endif
             }
         }
-        // ---- one stack entry per walking lane that holds no leaf --------------------------------------------
-        if (running && pending_leaf == RT_REF_NONE && sp != base) {
+        // ---- one entry per walking lane that holds no leaf ------------------------------------------------------
+        if (running && pending_leaf == RT_REF_NONE) {
 #ifdef RT_STATS
             ++dbg_steps;
 #endif
-            --sp;
-            const uint32_t ref = stack[sp * RT_WAVE];
-            const float entry = __uint_as_float(stack_t[sp * RT_WAVE]);
             const uint32_t pair_t = ((volatile uint32_t*)recs)[4 * owner + 1];     // closest hit any walker of the pair has
             const uint32_t pair_done = ((volatile uint32_t*)recs)[4 * owner + 3];
             float cut = RT_INF;                                      // boxes entered beyond this cannot matter
@@ -1204,31 +1213,47 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
                 if (pair_t != 0xFFFFFFFFu && __uint_as_float(pair_t) < lim) lim = __uint_as_float(pair_t);
                 cut = lim * RT_PRUNE_REL + prune_abs;
             }
-            if (pair_done) sp = base;                                // another walker has proven the shadow
-            else if (!(entry > cut)) {
-                if (ref & RT_REF_LEAF_BIT) {
-                    if ((ref >> RT_REF_COUNT_SHIFT) & 7u) pending_leaf = ref;
+            uint32_t next_ref = RT_REF_NONE;                        // a child to go on with, kept off the stack
+            float next_t = 0.0f;
+            if (pair_done) {
+                sp = base;                                           // another walker has proven the shadow
+            } else if (cur_ref != RT_REF_NONE && !(cur_t > cut)) {
+                if (cur_ref & RT_REF_LEAF_BIT) {
+                    if ((cur_ref >> RT_REF_COUNT_SHIFT) & 7u) pending_leaf = cur_ref;
                 } else {
-                    const float4 n0 = S.nodes[4 * ref], n1 = S.nodes[4 * ref + 1], n2 = S.nodes[4 * ref + 2], n3 = S.nodes[4 * ref + 3];
                     float tl, tr;
-                    bool hl = slab(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, lr.o, inv, tl);
-                    bool hr = slab(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, lr.o, inv, tr);
+                    bool hl = slab(nd0.x, nd0.y, nd0.z, nd0.w, nd1.x, nd1.y, lr.o, inv, tl);
+                    bool hr = slab(nd1.z, nd1.w, nd2.x, nd2.y, nd2.z, nd2.w, lr.o, inv, tr);
                     hl = hl && !(tl > cut);
                     hr = hr && !(tr > cut);
-                    uint32_t rl = __float_as_uint(n3.x), rr2 = __float_as_uint(n3.y);
-                    // reference order: push left, push right, so that right is popped first (intersect.rs:253-256);
-                    // on the fast path the nearer child is popped first instead
+                    uint32_t rl = __float_as_uint(nd3.x), rr2 = __float_as_uint(nd3.y);
+                    // reference order: the right child first, then the left one (intersect.rs:253-256 pushes left, then
+                    // right, and pops); on the fast path the nearer child comes first instead
                     if (fast && tl < tr) {
                         uint32_t tu = rl; rl = rr2; rr2 = tu;
                         float tf = tl; tl = tr; tr = tf;
                         bool tb = hl; hl = hr; hr = tb;
                     }
-                    if (hl) { stack[sp * RT_WAVE] = rl; stack_t[sp * RT_WAVE] = __float_as_uint(tl); ++sp; }
-                    if (hr) { stack[sp * RT_WAVE] = rr2; stack_t[sp * RT_WAVE] = __float_as_uint(tr); ++sp; }
+                    if (hr) {
+                        next_ref = rr2; next_t = tr;
+                        if (hl) { stack[sp * RT_WAVE] = rl; stack_t[sp * RT_WAVE] = __float_as_uint(tl); ++sp; }
+                    } else if (hl) {
+                        next_ref = rl; next_t = tl;
+                    }
                 }
             }
+            // what this lane looks at next: the child chosen above, else the top of its stack
+            if (next_ref == RT_REF_NONE && sp != base) {
+                --sp;
+                next_ref = stack[sp * RT_WAVE];
+                next_t = __uint_as_float(stack_t[sp * RT_WAVE]);
+            }
+            cur_ref = next_ref; cur_t = next_t;
+            if (cur_ref != RT_REF_NONE && !(cur_ref & RT_REF_LEAF_BIT)) {
+                nd0 = S.nodes[4 * cur_ref]; nd1 = S.nodes[4 * cur_ref + 1]; nd2 = S.nodes[4 * cur_ref + 2]; nd3 = S.nodes[4 * cur_ref + 3];
+            }
         }
-        if (running && pending_leaf == RT_REF_NONE && sp == base) {
+        if (running && pending_leaf == RT_REF_NONE && cur_ref == RT_REF_NONE && sp == base) {
             running = false;                                         // settled in the next service phase
             pending = true;
         }
