@@ -990,8 +990,8 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
     // come from a counter in device memory (one atomic per 64 pairs), so that waves with light pairs take more.
     // With less than 64 pairs per wave the chunks shrink, so that every wave gets some and shares the long ones.
     const bool one_chunk_each = (unsigned long long)n_waves * RT_WAVE >= n_items;
-    const uint32_t chunk_size = one_chunk_each ? (n_items + n_waves - 1) / n_waves : RT_WAVE;
-    uint32_t my_chunk = gwave, chunk_next = 0, chunk_end = 0;       // wave-uniform
+    const uint32_t n_chunks = one_chunk_each ? n_waves : (n_items + RT_WAVE - 1) / RT_WAVE;
+    uint32_t my_chunk = gwave, cur_chunk = 0, chunk_next = 0, chunk_end = 0;       // wave-uniform
     bool exhausted = false;
 
     // per-lane state of the walk
@@ -1071,10 +1071,12 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
                     }
                     my_chunk = n_waves + taken;
                 }
-                if ((unsigned long long)my_chunk * chunk_size >= n_items) exhausted = true;
+                // chunk c holds the pairs c, c + n_chunks, c + 2 * n_chunks, ...
+                if (my_chunk >= n_chunks || my_chunk >= n_items) exhausted = true;
                 else {
-                    chunk_next = my_chunk * chunk_size;
-                    chunk_end = (n_items - chunk_next < chunk_size) ? n_items : chunk_next + chunk_size;
+                    cur_chunk = my_chunk;
+                    chunk_next = 0;
+                    chunk_end = (n_items - my_chunk + n_chunks - 1) / n_chunks;
                     my_chunk = 0xFFFFFFFFu;                          // the next one is asked for when it is needed
                 }
             }
@@ -1084,7 +1086,9 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
             if (!running) {
                 const uint32_t rank = __popcll(idle_mask & ((1ull << lane) - 1ull));
                 if (rank < avail) {
-                    const size_t fat = locate(pre, F.n_seg, F.seg_fat, chunk_next + rank);
+                    // Element j of chunk c is pair c + j * n_chunks: neighbouring pairs (similar rays, similar cost) go to
+                    // different chunks.  A 64-byte item is a cache line of its own either way.
+                    const size_t fat = locate(pre, F.n_seg, F.seg_fat, cur_chunk + (chunk_next + rank) * n_chunks);
                     const float4 q0 = F.fat_items[4 * fat], q1 = F.fat_items[4 * fat + 1], q2 = F.fat_items[4 * fat + 2],
                                  q3 = F.fat_items[4 * fat + 3];
                     lr.o = mk(q0.x, q0.y, q0.z);
