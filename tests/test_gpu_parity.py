@@ -246,3 +246,30 @@ def test_kernel_timing_mode(scenes_dir, model_dir):
     assert {n: c for n, (ms, c) in k.items()} == {"rt_setup": 5, "rt_root": 5, "rt_traverse": 5, "rt_shade": 5, "rt_phong": 4}
     assert all(ms > 0.0 for ms, c in k.values())
     assert sum(ms for ms, c in k.values()) <= trace * 1.05
+
+
+def test_hip_renderer_mirrors_gpu_renderer(scenes_dir, model_dir):
+    """HipRenderer has GpuRenderer's four methods (gpu_renderer.rs:44-68, 280, 356-364): new / render into an
+    RGBA canvas / resize_screen / turn_camera; each frame equals the oracle's after the same calls."""
+    from rust_raytracer_amd import HipRenderer
+    path = os.path.join(scenes_dir, "reflective_bunnies.json")
+    r = HipRenderer(path, model_dir, width=256, height=144)
+    s = orc.OracleScene.from_file(path, model_dir)
+    try:
+        s.resize(256, 144)
+        canvas = np.zeros((144, 256, 4), dtype=np.uint8)
+        assert r.render(canvas) is canvas
+        want = s.render(channels=4, aux=False)["rgb"]
+        assert (np.abs(canvas.astype(int) - want.astype(int)).max(axis=2) <= 1).mean() >= 0.999
+        assert (canvas[..., 3] == 255).all()
+        r.turn_camera(10.0, 20.0, 60.0, 5.0)
+        s.turn_camera(10.0, 20.0, 60.0, 5.0)
+        r.resize_screen(200, 120)
+        s.resize(200, 120)
+        assert r.size == (200, 120)
+        got = r.render(channels=3)
+        want = s.render(aux=False)["rgb"]
+        assert got.shape == (120, 200, 3)
+        assert (np.abs(got.astype(int) - want.astype(int)).max(axis=2) <= 1).mean() >= 0.999
+    finally:
+        r.close()
