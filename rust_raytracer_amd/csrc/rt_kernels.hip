@@ -447,6 +447,39 @@ __device__ __forceinline__ uint32_t locate(const uint32_t* pre, uint32_t n_seg, 
     return lo * seg_cap + (v - pre[lo]);          // the overflow segment starts at (n_seg - 1) * seg_cap
 }
 
+// The same for the 64 consecutive elements v0 .. v0 + 63 a wave handles together (lane l gets element v0 + l;
+// must be called by all lanes of the wave; elements at or beyond `total` get an unspecified slot).  The
+// wave finds the segment of v0 in two cooperative steps - 64 samples of the table, then the bracket between
+// two samples - instead of ten dependent ones, and each lane walks on from there.
+__device__ __forceinline__ uint32_t locate_chunk(const uint32_t* pre, uint32_t n_seg, uint32_t seg_cap, uint32_t v0, uint32_t total,
+                                                 uint32_t lane) {
+    uint32_t lo = 0, span = n_seg + 1;                     // the answer for v0 lies in [lo, lo + span)
+    while (span > 1) {
+        const uint32_t stride = (span + RT_WAVE - 1) / RT_WAVE;
+        const uint32_t i = lo + lane * stride;
+        const bool below = lane * stride < span && pre[i] <= v0;
+        const uint32_t cnt = __popcll(__ballot(below));    // pre[lo] <= v0 always, so cnt >= 1
+        lo += (cnt - 1) * stride;
+        span = (lo + stride <= n_seg + 1) ? stride : n_seg + 1 - lo;
+    }
+    uint32_t seg = lo < n_seg ? lo : n_seg - 1;
+    const uint32_t v = v0 + lane;
+    if (v < total) {
+        // pre[n_seg] = total > v ends the walk; a long run of empty segments is crossed by bisection
+        uint32_t steps = 0;
+        while (pre[seg + 1] <= v) {
+            ++seg;
+            if (++steps == 4) {
+                uint32_t a = seg, b = n_seg;
+                while (b - a > 1) { const uint32_t mid = (a + b) >> 1; if (pre[mid] <= v) a = mid; else b = mid; }
+                seg = a;
+                break;
+            }
+        }
+    }
+    return seg * seg_cap + (v - pre[seg]);
+}
+
 // A slot of this block's output segment for every lane that wants one (RT_REF_NONE otherwise, or when
 // even the overflow segment is full).  Must be called by all lanes of the wave.
 __device__ __forceinline__ uint32_t append_slot(bool want, uint32_t* lds_counter, uint32_t seg_cap, uint32_t n_seg,
@@ -676,7 +709,10 @@ __global__ void __launch_bounds__(RT_SETUP_THREADS) rt_setup(const DScene S, con
         const unsigned long long tc0 = clock64();
         ts[2] += 1;
 #endif
-        if (active) { gi = locate(pre, F.n_seg, F.seg_rays, v); rr = load_rec(rays, gi); }
+        {
+            const uint32_t at = locate_chunk(pre, F.n_seg, F.seg_rays, c * RT_WAVE, n_rays, lane);
+            if (active) { gi = at; rr = load_rec(rays, gi); }
+        }
         const Ray r = rr.ray;
         const ShadowSpec ss = shadow_spec(S, rr);
 #ifdef RT_STATS
@@ -899,8 +935,8 @@ __global__ void __launch_bounds__(RT_ROOT_THREADS) rt_root(const DScene S, const
         const uint32_t v = c * RT_WAVE + lane;
         bool pass = false;
         float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
+        const uint32_t item = locate_chunk(pre, F.n_seg, F.seg_items, c * RT_WAVE, n_items, lane);
         if (v < n_items) {
-            const uint32_t item = locate(pre, F.n_seg, F.seg_items, v);
             const uint2 it = F.items[item];
             if (!(it.y & RT_ITEM_DONE)) {
                 const uint32_t gi = it.x, ii = it.y;
@@ -1301,7 +1337,10 @@ __global__ void __launch_bounds__(RT_SHADE_THREADS) rt_shade(const DScene S, con
         cur.throughput = 0.0f;
         cur.meta = 0;
         unsigned long long key = RT_KEY_NONE;
-        if (active) { gi = locate(pre, F.n_seg, F.seg_rays, v); cur = load_rec(rays, gi); key = F.best[gi]; }
+        {
+            const uint32_t at = locate_chunk(pre, F.n_seg, F.seg_rays, c * RT_WAVE, n_rays, lane);
+            if (active) { gi = at; cur = load_rec(rays, gi); key = F.best[gi]; }
+        }
         const bool have = key != RT_KEY_NONE;
         const float best_t = __uint_as_float((uint32_t)(key >> 32));
         const uint32_t order = (uint32_t)key;
@@ -1467,8 +1506,8 @@ __global__ void __launch_bounds__(RT_PHONG_THREADS) rt_phong(const DScene S, con
     const uint32_t n_waves = gridDim.x * (blockDim.x / RT_WAVE);
     for (uint32_t c = gwave; (unsigned long long)c * RT_WAVE < n_hits; c += n_waves) {
         const uint32_t v = c * RT_WAVE + lane;
+        const uint32_t hs = locate_chunk(pre, F.n_seg, F.seg_hits, c * RT_WAVE, n_hits, lane);
         if (v >= n_hits) continue;
-        const uint32_t hs = locate(pre, F.n_seg, F.seg_hits, v);
         const float4* H = F.hits[q] + 3 * (size_t)hs;
         const float4 h0 = H[0], h1 = H[1], h2 = H[2];
         const V3 position = mk(h0.x, h0.y, h0.z), n = mk(h1.x, h1.y, h1.z), view = mk(h2.x, h2.y, h2.z);
