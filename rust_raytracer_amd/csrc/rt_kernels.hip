@@ -750,18 +750,48 @@ __global__ void __launch_bounds__(RT_SETUP_THREADS) rt_setup(const DScene S, con
         float lw = ss.limit_world;
         if (have && best_t < lw) lw = best_t;
         const float lw_cut = lw * 1.000244140625f;
-        for (uint32_t ii = 0; ii < S.n_instances; ++ii) {
-            const DInstance& inst = S.instances[ii];
-            bool want_item = false;
-            if (active && !settled && inst.root_ref != RT_REF_NONE) {
-                // the box is only trusted for origins within cull_origin_limit; farther rays always get a work item
-                float tmin_w;
-                want_item = !(o_l1 < inst.cull_origin_limit) ||
-                            (slab(inst.world_lo[0], inst.world_lo[1], inst.world_lo[2], inst.world_hi[0], inst.world_hi[1],
-                                  inst.world_hi[2], r.o, inv_w, tmin_w) && !(tmin_w > lw_cut));
+        // Eight instances at a time: all the tests first, then one reservation in this block's list segment for
+        // the whole group.  Within the group the pairs of instance k come before those of instance k + 1, so a
+        // ray's pairs keep the instances' Vec order.
+        const unsigned long long lanes_below = (1ull << lane) - 1ull;
+        for (uint32_t g0 = 0; g0 < S.n_instances; g0 += 8) {
+            unsigned long long wants[8];
+            uint32_t group_total = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k) {
+                bool want_item = false;
+                if (g0 + k < S.n_instances) {
+                    const DInstance& inst = S.instances[g0 + k];
+                    if (active && !settled && inst.root_ref != RT_REF_NONE) {
+                        // the box is only trusted for origins within cull_origin_limit; farther rays always get a pair
+                        float tmin_w;
+                        want_item = !(o_l1 < inst.cull_origin_limit) ||
+                                    (slab(inst.world_lo[0], inst.world_lo[1], inst.world_lo[2], inst.world_hi[0], inst.world_hi[1],
+                                          inst.world_hi[2], r.o, inv_w, tmin_w) && !(tmin_w > lw_cut));
+                    }
+                }
+                wants[k] = __ballot(want_item);
+                group_total += __popcll(wants[k]);
             }
-            uint32_t slot = append_slot(want_item, &out_n, F.seg_items, F.n_seg, F.item_counts, F.ovf_items, F.overflow, lane);
-            if (slot != RT_REF_NONE) F.items[slot] = make_uint2(gi, ii);
+            if (group_total == 0) continue;
+            uint32_t at = 0;
+            if (lane == 0) at = atomicAdd(&out_n, group_total);
+            at = __builtin_amdgcn_readfirstlane(at);
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k) {
+                if ((wants[k] >> lane) & 1ull) {
+                    const uint32_t idx = at + __popcll(wants[k] & lanes_below);
+                    uint32_t slot = RT_REF_NONE;
+                    if (idx < F.seg_items) slot = blockIdx.x * F.seg_items + idx;
+                    else {
+                        const uint32_t j = atomicAdd(&F.item_counts[F.n_seg - 1], 1u);      // the shared overflow segment
+                        if (j < F.ovf_items) slot = (F.n_seg - 1) * F.seg_items + j;
+                        else *F.overflow = 1u;
+                    }
+                    if (slot != RT_REF_NONE) F.items[slot] = make_uint2(gi, g0 + k);
+                }
+                at += __popcll(wants[k]);
+            }
         }
 #ifdef RT_STATS
         const unsigned long long tc3 = clock64();
