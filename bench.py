@@ -28,6 +28,10 @@ WORKLOADS = {
     "cornell_box_720p": ("cornell_box.json", 1280, 720, 10),
     "mirror_sphere_1080p_depth16": ("mirror_sphere.json", 1920, 1080, 16),
     "infinity_santa_1080p_depth16": ("infinity_santa.json", 1920, 1080, 16),
+    # synthetic many-mesh scenes (rust_raytracer_amd/synthetic.py): grid x grid instances over `meshes` distinct
+    # jittered icospheres of 81 920 triangles each - a working set far beyond the caches
+    "instance_grid_2p6m_4k": ("synthetic:grid=8,meshes=32,level=6", 3840, 2160, 10),
+    "instance_grid_10m_4k": ("synthetic:grid=16,meshes=128,level=6", 3840, 2160, 10),
 }
 
 # Algorithmic work of the reference's un-pruned traversal (what intersect.rs would execute), per
@@ -106,10 +110,20 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     scene_file, width, height, max_depth = WORKLOADS[args.workload]
-    scene_path = os.path.join(ROOT, "scenes", scene_file)
     model_dir = args.model_dir
-    if model_dir is None:
-        model_dir = meshes.ensure_model_dir(os.path.join("/tmp", "rust_raytracer_amd_models_rank%d_%d" % (rank, os.getuid())))
+    if scene_file.startswith("synthetic:"):
+        from rust_raytracer_amd import synthetic
+        opts = dict(kv.split("=") for kv in scene_file[len("synthetic:"):].split(","))
+        if model_dir is None:
+            model_dir = os.path.join("/tmp", "rust_raytracer_amd_grid_rank%d_%d" % (rank, os.getuid()))
+        os.makedirs(model_dir, exist_ok=True)
+        scene_path = os.path.join(model_dir, args.workload + ".json")
+        with open(scene_path, "w") as fh:
+            fh.write(synthetic.instance_grid_scene(model_dir, int(opts["grid"]), int(opts["meshes"]), int(opts["level"]), width, height))
+    else:
+        scene_path = os.path.join(ROOT, "scenes", scene_file)
+        if model_dir is None:
+            model_dir = meshes.ensure_model_dir(os.path.join("/tmp", "rust_raytracer_amd_models_rank%d_%d" % (rank, os.getuid())))
 
     host = native.HostScene.load(scene_path, model_dir)
     host.resize_screen(width, height)
@@ -183,7 +197,8 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "scene": scene_file, "width": w, "height": h, "max_depth": max_depth,
-                       "mesh": "bunny.obj stand-in (procedural, %d triangles) unless --model-dir holds a real one" % n_tris
+                       "mesh": ("%d mesh triangles, procedural" % n_tris if scene_file.startswith("synthetic:") else
+                                "stand-in meshes (procedural, %d triangles) unless --model-dir holds the real ones" % n_tris)
                                if n_tris else "none",
                        "rays_per_frame": rays_per_frame, "primary": int(rays[1]), "shadow": int(rays[2]),
                        "reflected": int(rays[3]), "transmitted": int(rays[4]),
