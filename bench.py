@@ -152,6 +152,7 @@ def main():
 
     for _ in range(args.warmup):
         sf.step()
+        torch.cuda.synchronize()      # a frame whose ray lists overflowed is noticed by the next one: let it finish
     barrier()
     trace_ms = []
     t0 = time.perf_counter()

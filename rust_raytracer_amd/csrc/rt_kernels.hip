@@ -11,13 +11,16 @@
 //    throughput * local colour to its pixel.  Sums are kept in 2^-40 fixed point with integer
 //    atomics, so the result does not depend on the order in which rays finish.
 //  * All rays of one recursion depth - and the shadow rays of the hits one depth up - form a list
-//    in HBM (32 B per ray).  Each depth is four dense launches over such lists:
-//      A  rt_setup     analytic primitives + root-box test of every mesh instance per ray; emits
-//                      one BVH work item per (ray, instance) that needs a walk
-//      B  rt_traverse  BVH walk, one work item per lane, lanes refilled as they finish - every
-//                      lane that is busy is busy with the same code
-//      C  rt_shade     closest hit -> hit point, material, child rays and shadow rays
-//      D  rt_phong     Phong sums of the previous depth's hits once their shadow rays are back
+//    in HBM (32 B per ray).  Each depth is a sequence of dense launches over such lists:
+//      A   rt_setup       per ray: analytic primitives; per instance a world-space culling box -> one
+//                         (ray, instance) pair per instance the ray can touch
+//      A'  rt_setup_slow  the few rays rt_setup does not treat (non-finite components, degenerate instance
+//                         matrices), in the reference's exact evaluation order; usually an empty launch
+//      A2  rt_root        per pair: the mesh-local ray and the exact root-box test -> 64-byte walk item
+//      B   rt_traverse    BVH walk, one walk item per lane, lanes refilled as they finish - every lane
+//                         that is busy is busy with the same code
+//      C   rt_shade       closest hit -> hit point, material, child rays and shadow rays
+//      D   rt_phong       Phong sums of the previous depth's hits once their shadow rays are back
 //    Splitting by kind of work is what keeps the 64 lanes of a wave busy: in a one-kernel version
 //    fewer than 5 % of the lanes had a BVH node to visit in a given round.
 //  * Lists are appended to without device-wide atomics (about 10 ns each when contended, all
