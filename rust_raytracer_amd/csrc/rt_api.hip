@@ -488,7 +488,7 @@ static int ensure_frame(RtScene* s, const Geometry& g, uint32_t max_depth, bool 
         s->pixel_clear_bytes = (size_t)3 * g.n_pixels * sizeof(long long) + (size_t)g.n_pixels * sizeof(unsigned int);
         s->counter_words = 7 * (size_t)f.n_seg + 2 * (RT_MAX_DEPTH_LIMIT + 2) + s->stats_words;
         if ((rc = frame_alloc(s, s->pixel_clear_bytes / sizeof(long long) + 1, &pixels)) ||
-            (rc = frame_alloc(s, s->counter_words, &counters)) ||
+            (rc = frame_alloc(s, s->counter_words, &counters)) || (rc = frame_alloc(s, (size_t)3 * g.n_pixels, &f.acc_big)) ||
             (rc = frame_alloc(s, 2 * ray_slots, &f.rays[0])) || (rc = frame_alloc(s, 2 * ray_slots, &f.rays[1])) ||
             (rc = frame_alloc(s, ray_slots, &f.best)) ||
             (rc = frame_alloc(s, item_slots, &f.items)) || (rc = frame_alloc(s, item_slots, &f.item_results)) ||
@@ -496,6 +496,7 @@ static int ensure_frame(RtScene* s, const Geometry& g, uint32_t max_depth, bool 
             (rc = frame_alloc(s, 3 * hit_slots, &f.hits[0])) || (rc = frame_alloc(s, 3 * hit_slots, &f.hits[1])) ||
             (rc = frame_alloc(s, flag_bytes, &f.shadow_flags[0])) || (rc = frame_alloc(s, flag_bytes, &f.shadow_flags[1])))
             return rc;
+        HIP_TRY(hipMemset(f.acc_big, 0, (size_t)3 * g.n_pixels * sizeof(double)));     // rt_resolve keeps it zero afterwards
         f.acc = pixels;
         f.poison = reinterpret_cast<unsigned int*>(pixels + (size_t)3 * g.n_pixels);
         unsigned int* c = counters;

@@ -122,6 +122,7 @@ struct DFrame {
     uint32_t seg_fat, ovf_fat;       // pairs that pass the exact root-box test
     uint32_t seg_hits, ovf_hits;
     long long* acc;                  // [3][n_pixels] fixed-point colour sums, 2^-40 units
+    double* acc_big;                 // [3][n_pixels] sums of the rare contributions beyond 2^22
     unsigned int* poison;            // [n_pixels] non-finite contributions, see rt_kernels.hip
     unsigned int* aux_flags;         // [n_pixels] or null
     unsigned int* aux_prim;          // [n_pixels] or null

@@ -287,15 +287,24 @@ __device__ __forceinline__ float fresnel_reflection(V3 refl_d, V3 trans_d, V3 N,
 }
 
 // ---- pixel sums --------------------------------------------------------------------------------
-// poison bits per channel c: bit c = NaN, bit 3+c = +inf (or beyond the fixed-point range), bit 6+c = -inf
+// Contributions below 2^22 in magnitude go to a sum in 2^-40 units (exact for every float >= 2^-16, and far
+// finer than the 8-bit result needs below that): integer sums, so the result does not depend on the order in
+// which rays finish.  Larger finite ones - Fresnel factors can blow up, and multiply along a path, where a shading
+// normal disagrees with the geometry - go to a second sum in double precision, whose rounding is far below what
+// such a pixel's float arithmetic in the reference resolves.
+// poison bits per channel c: bit c = NaN, bit 3+c = +inf, bit 6+c = -inf; bit 9: the second sum was used.
 #define RT_FIXED_ONE 1099511627776.0     // 2^40
 #define RT_FIXED_LIMIT 4194304.0f        // 2^22
+#define RT_POISON_BIG 512u
 
 __device__ __forceinline__ void add_channel(const DFrame& F, uint32_t pixel, int c, float v) {
     if (v == 0.0f) return;
     if (fabsf(v) < RT_FIXED_LIMIT) {
         long long q = __double2ll_rn((double)v * RT_FIXED_ONE);
         atomicAdd(reinterpret_cast<unsigned long long*>(F.acc + (size_t)c * F.n_pixels + pixel), (unsigned long long)q);
+    } else if (finite1(v)) {
+        atomicAdd(F.acc_big + (size_t)c * F.n_pixels + pixel, (double)v);
+        atomicOr(F.poison + pixel, RT_POISON_BIG);
     } else {
         unsigned int bit = (v != v) ? (1u << c) : (v > 0.0f ? (8u << c) : (64u << c));
         atomicOr(F.poison + pixel, bit);
@@ -1583,7 +1592,12 @@ __global__ void rt_resolve(const DFrame F, uint8_t* out, uint32_t bytes_per_pixe
     if (inside) {
         unsigned int poison = F.poison[p];
         for (int c = 0; c < 3; ++c) {
-            float v = (float)((double)F.acc[(size_t)c * F.n_pixels + p] * (1.0 / RT_FIXED_ONE));
+            double sum = (double)F.acc[(size_t)c * F.n_pixels + p] * (1.0 / RT_FIXED_ONE);
+            if (poison & RT_POISON_BIG) {
+                sum += F.acc_big[(size_t)c * F.n_pixels + p];
+                F.acc_big[(size_t)c * F.n_pixels + p] = 0.0;        // only pixels that used it clear it: no per-frame clear
+            }
+            float v = (float)sum;
             bool is_nan = (poison >> c) & 1u, pinf = (poison >> (3 + c)) & 1u, ninf = (poison >> (6 + c)) & 1u;
             if (is_nan || (pinf && ninf)) v = __uint_as_float(0x7FC00000u);
             else if (pinf) v = __uint_as_float(0x7F800000u);

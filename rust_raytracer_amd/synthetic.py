@@ -105,3 +105,69 @@ def orbit_poses(n: int, centre=(0.0, 0.0, -6.0), radius: float = 8.0, pitch_degr
         position = (centre[0] + radius * math.sin(yaw), centre[1] + lift, centre[2] + radius * math.cos(yaw))
         poses.append((position, (pitch, yaw, 0.0)))
     return poses
+
+
+def random_scene(model_dir: str, seed: int, width: int = 96, height: int = 64) -> str:
+    """A random small scene in the reference's scene-file schema, for fuzzing the device path against the
+    oracle: 0-3 lights (point and directional), 4-6 materials of all three types, 0-3 planes, 0-4 spheres, 0-3
+    free triangles, 1-2 meshes (small icospheres, written to model_dir) and 0-6 instances with arbitrary rotations,
+    non-uniform scales (down to nearly flat) and optional material overrides, either background."""
+    import random
+    rng = random.Random(seed)
+    u = rng.uniform
+    names = write_grid_meshes(model_dir, 2, 2)
+
+    def col(lo=0.0, hi=1.0):
+        return _rgb(u(lo, hi), u(lo, hi), u(lo, hi))
+
+    kinds = ["Phong", "ReflectAndPhong", "ReflectAndRefract"]
+    materials = []
+    for k in range(rng.randint(4, 6)):
+        mat = {"name": "m%d" % k, "emissive": col(0, 0.1), "ambient": col(0, 0.5), "diffuse": col(0, 0.8), "specular": col(0, 0.8),
+               "shininess": rng.choice([0.5, 1, 8, 30]), "material_type": kinds[k % 3] if k < 3 else rng.choice(kinds)}
+        if mat["material_type"] == "ReflectAndRefract":
+            mat["material_type"] = {"ReflectAndRefract": {"index_inner": u(1.1, 1.7), "index_outer": 1.0}}
+        materials.append(mat)
+    mname = lambda: "m%d" % rng.randrange(len(materials))
+    # Refraction only where the shading normal is the geometric one (spheres, planes): with the random vertex normals
+    # of the triangles and the non-uniformly scaled mesh normals (transformed by rotation_scale, not its inverse
+    # transpose, intersect.rs:313), Fresnel factors reach 1e20 and the reference's own float colour is noise.
+    opaque = [k for k, mat in enumerate(materials) if isinstance(mat["material_type"], str)]
+    oname = lambda: "m%d" % rng.choice(opaque)
+    lights = []
+    for _ in range(rng.randint(0, 3)):
+        directional = rng.random() < 0.3
+        lights.append({"position": {"x": u(-8, 8), "y": u(1, 9), "z": u(-12, 4), "w": 0 if directional else 1},
+                       "color": {"ambient": col(0, 0.3), "diffuse": col(0.2, 0.8), "specular": col(0, 0.6)}})
+    planes = [{"normal": _xyz(u(-0.3, 0.3), 1, u(-0.3, 0.3)), "distance": u(-3, -1), "material": mname()}]
+    for _ in range(rng.randint(0, 2)):
+        planes.append({"normal": _xyz(u(-1, 1), u(-1, 1), u(0.2, 1)), "distance": u(-14, -8), "material": mname()})
+    if rng.random() < 0.2:
+        planes = []
+    spheres = [{"center": _xyz(u(-4, 4), u(-1, 3), u(-10, -3)), "radius": u(0.3, 1.5), "material": mname()}
+               for _ in range(rng.randint(0, 4))]
+    triangles = []
+    for _ in range(rng.randint(0, 3)):
+        c = (u(-4, 4), u(-1, 3), u(-10, -4))
+        vs = [_xyz(c[0] + u(-2, 2), c[1] + u(-2, 2), c[2] + u(-2, 2)) for _ in range(3)]
+        n = _xyz(u(-1, 1), u(-1, 1), u(0.1, 1))
+        triangles.append({"vertices": vs, "normals": [n, n, n], "material": oname()})
+    instances = []
+    for _ in range(rng.randint(0, 6)):
+        inst = {"mesh": "grid_mesh_%d" % rng.randrange(2), "position": _xyz(u(-4, 4), u(-1, 3), u(-11, -3)),
+                "orientation_degrees": _xyz(u(0, 360), u(0, 360), u(0, 360)),
+                "scale": _xyz(u(0.05, 1.8), u(0.3, 1.8), u(0.3, 1.8))}
+        if rng.random() < 0.6:
+            inst["material_override"] = oname()
+        instances.append(inst)
+    scene = {
+        "camera": {"position": _xyz(u(-1, 1), u(0, 2), u(0, 3)), "orientation_degrees": _xyz(u(-25, 5), u(-20, 20), u(-10, 10)),
+                   "screen_dimensions": [width, height], "y_fov_degrees": u(40, 80), "z_near": 0.1, "z_far": 40,
+                   "use_perspective": True, "ortho_world_height": 10},
+        "background": "ColoredDirection" if rng.random() < 0.5 else {"SolidColor": col()},
+        "lights": lights, "materials": materials, "planes": planes, "spheres": spheres, "triangles": triangles,
+        "meshes": [{"name": "grid_mesh_%d" % k, "file_name": names[k], "winding_order": rng.choice(["CounterClockwise", "Clockwise"]),
+                    "material": oname()} for k in range(2)],
+        "mesh_instances": instances,
+    }
+    return json.dumps(scene)

@@ -273,3 +273,19 @@ def test_hip_renderer_mirrors_gpu_renderer(scenes_dir, model_dir):
         assert (np.abs(got.astype(int) - want.astype(int)).max(axis=2) <= 1).mean() >= 0.999
     finally:
         r.close()
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_random_scenes(tmp_path_factory, block):
+    """Fuzz: random small scenes - every primitive kind, point and directional lights or none, the three material
+    types, instances with arbitrary rotations and very non-uniform scales, both winding orders, both backgrounds.
+    Ids, flags and ray counts must agree exactly with the oracle, colours within the usual tolerance."""
+    from rust_raytracer_amd import synthetic
+    d = str(tmp_path_factory.mktemp("fuzz_models"))
+    for seed in range(block * 12, block * 12 + 12):
+        s = orc.OracleScene.from_text(synthetic.random_scene(d, seed), d)
+        got, want = render_both(s, max_depth=6)
+        try:
+            assert_parity(got, want, min_within_1=0.995)
+        except AssertionError as e:
+            raise AssertionError("seed %d: %s" % (seed, e))
