@@ -1124,8 +1124,8 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
             if (pending) {
                 pending = false;
                 if (atomicSub(&recs[4 * owner + 2], 1u) == 1u) {
-                    const uint32_t win_slot = ((volatile uint32_t*)recs)[4 * owner];
-                    if (((volatile uint32_t*)recs)[4 * owner + 1] != 0xFFFFFFFFu) {
+                    const uint32_t win_slot = __atomic_load_n(&recs[4 * owner], __ATOMIC_RELAXED);
+                    if (__atomic_load_n(&recs[4 * owner + 1], __ATOMIC_RELAXED) != 0xFFFFFFFFu) {
                         if (!(m_have && m_slot == win_slot)) {
                             // another walker found it: the test is a pure function of ray and triangle
                             const float4 h0 = S.tri_hot[3 * win_slot], h1 = S.tri_hot[3 * win_slot + 1], h2 = S.tri_hot[3 * win_slot + 2];
@@ -1287,8 +1287,8 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
 #ifdef RT_STATS
             ++dbg_steps;
 #endif
-            const uint32_t pair_t = ((volatile uint32_t*)recs)[4 * owner + 1];     // closest hit any walker of the pair has
-            const uint32_t pair_done = ((volatile uint32_t*)recs)[4 * owner + 3];
+            const uint32_t pair_t = __atomic_load_n(&recs[4 * owner + 1], __ATOMIC_RELAXED);     // closest hit any walker of the pair has
+            const uint32_t pair_done = __atomic_load_n(&recs[4 * owner + 3], __ATOMIC_RELAXED);
             float cut = RT_INF;                                      // boxes entered beyond this cannot matter
             if (fast) {
                 float lim = (m_have && m_t < limit) ? m_t : limit;
