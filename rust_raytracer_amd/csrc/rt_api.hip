@@ -41,6 +41,9 @@ static int fail(int code, const char* fmt, ...) {
         if (e_ != hipSuccess) return fail(RT_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
+// instance counts above this get a range tree over the culling boxes (rt_setup walks it instead of scanning)
+#define RT_RANGE_TREE_MIN 16
+
 struct RtScene {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -365,6 +368,50 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device_id, RtScene**
     s->d.n_lights = desc->n_lights; s->d.n_planes = desc->n_planes; s->d.n_spheres = desc->n_spheres;
     s->d.n_triangles = desc->n_triangles; s->d.n_instances = desc->n_mesh_instances;
     s->d.stack_entries = stack_entries;
+    // range tree over the instances' culling boxes (see DScene), for scenes where a linear scan per ray hurts
+    std::vector<float4> range_nodes;
+    std::vector<float> range_limits;
+    uint32_t range_depth = 0;
+    {
+        bool usable = instances.size() > RT_RANGE_TREE_MIN;
+        for (const DInstance& di : instances) usable = usable && (di.cullable || di.root_ref == RT_REF_NONE);
+        if (usable) {
+            struct Build {
+                const std::vector<DInstance>& inst; std::vector<float4>& nodes; std::vector<float>& limits; uint32_t depth = 0;
+                // returns the node of the range [a, b)
+                uint32_t run(uint32_t a, uint32_t b, uint32_t level, float lo[3], float hi[3], float* limit) {
+                    if (level > depth) depth = level;
+                    const uint32_t k = (uint32_t)limits.size();
+                    limits.push_back(0.0f);
+                    nodes.push_back(f4(0, 0, 0, 0)); nodes.push_back(f4(0, 0, 0, 0));
+                    if (b - a == 1) {
+                        const DInstance& di = inst[a];
+                        const bool empty = di.root_ref == RT_REF_NONE;           // an empty mesh: never a pair
+                        for (int c = 0; c < 3; ++c) { lo[c] = empty ? INFINITY : di.world_lo[c]; hi[c] = empty ? -INFINITY : di.world_hi[c]; }
+                        *limit = empty ? INFINITY : di.cull_origin_limit;
+                        nodes[2 * k] = f4(lo[0], lo[1], lo[2], bits(empty ? 0xFFFFFFFFu : (0x80000000u | a)));
+                        nodes[2 * k + 1] = f4(hi[0], hi[1], hi[2], bits(0u));
+                        limits[k] = *limit;
+                        return k;
+                    }
+                    const uint32_t mid = a + (b - a) / 2;
+                    float llo[3], lhi[3], rlo[3], rhi[3], ll, rl;
+                    const uint32_t left = run(a, mid, level + 1, llo, lhi, &ll), right = run(mid, b, level + 1, rlo, rhi, &rl);
+                    for (int c = 0; c < 3; ++c) { lo[c] = std::min(llo[c], rlo[c]); hi[c] = std::max(lhi[c], rhi[c]); }
+                    *limit = std::min(ll, rl);
+                    nodes[2 * k] = f4(lo[0], lo[1], lo[2], bits(left));
+                    nodes[2 * k + 1] = f4(hi[0], hi[1], hi[2], bits(right));
+                    limits[k] = *limit;
+                    return k;
+                }
+            } build{instances, range_nodes, range_limits};
+            float lo[3], hi[3], limit;
+            build.run(0, (uint32_t)instances.size(), 1, lo, hi, &limit);
+            range_depth = build.depth + 1;
+        }
+    }
+    s->d.n_range_nodes = (uint32_t)range_limits.size();
+    s->d.range_depth = range_depth;
     s->d.all_cullable = 1;
     for (const DInstance& di : instances) {
         if (di.root_ref == RT_REF_NONE) continue;                  // an empty mesh is never tested
@@ -373,6 +420,7 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device_id, RtScene**
     if ((rc = upload(s, lights, &s->d.lights)) || (rc = upload(s, materials, &s->d.materials)) ||
         (rc = upload(s, planes, &s->d.planes)) || (rc = upload(s, spheres, &s->d.spheres)) ||
         (rc = upload(s, triangles, &s->d.triangles)) || (rc = upload(s, instances, &s->d.instances)) ||
+        (rc = upload(s, range_nodes, &s->d.range_nodes)) || (rc = upload(s, range_limits, &s->d.range_limits)) ||
         (rc = upload(s, nodes, &s->d.nodes)) || (rc = upload(s, hot, &s->d.tri_hot)) || (rc = upload(s, cold, &s->d.tri_cold)))
         return bail(rc);
     s->list_blocks = (uint32_t)s->n_cus * 4;

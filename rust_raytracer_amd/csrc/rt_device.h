@@ -83,6 +83,16 @@ struct DScene {
     uint32_t n_lights, n_planes, n_spheres, n_triangles, n_instances;
     uint32_t stack_entries;      // per-lane traversal stack entries any mesh can need (<= RT_BVH_STACK_LEN)
     uint32_t all_cullable;       // every instance has a usable culling box (DInstance::cullable)
+    // Scenes with many instances: a binary tree over index ranges of the instances (node 0 = all of them, children
+    // split a range in the middle), each node with the union of its instances' culling boxes.  Visiting the left
+    // child first meets the instances in Vec order, which is the order the pairs of a ray must be emitted in.
+    //   inner node k: range_nodes[2k] = (box min, bits left child node), [2k+1] = (box max, bits right child node)
+    //   leaf k (one instance): range_nodes[2k].w = bits (0x80000000 | instance), or 0xFFFFFFFF for an empty mesh
+    //   range_limits[k] = smallest cull_origin_limit in the range
+    uint32_t n_range_nodes;      // 0: rt_setup scans the instances linearly
+    uint32_t range_depth;        // stack entries a walk of the tree can need
+    const float4* range_nodes;
+    const float* range_limits;
     const DLight* lights;
     const RtMaterial* materials;
     const DPlane* planes;

@@ -762,11 +762,41 @@ __global__ void __launch_bounds__(RT_SETUP_THREADS) rt_setup(const DScene S, con
         float lw = ss.limit_world;
         if (have && best_t < lw) lw = best_t;
         const float lw_cut = lw * 1.000244140625f;
-        // Eight instances at a time: all the tests first, then one reservation in this block's list segment for
-        // the whole group.  Within the group the pairs of instance k come before those of instance k + 1, so a
+        if (S.n_range_nodes) {
+            // Many instances: each lane walks the range tree, left child first, so it meets its instances in Vec order.
+            uint32_t* walk = stage + stage_words + threadIdx.x;          // entry e of this lane: walk[e * blockDim.x]
+            uint32_t sp = 0;
+            if (active && !settled) { walk[0] = 0u; sp = 1; }
+            while (sp) {
+                const uint32_t k = walk[--sp * blockDim.x];
+                const float4 q0 = S.range_nodes[2 * k], q1 = S.range_nodes[2 * k + 1];
+                float tmin_w;
+                const bool pass = !(o_l1 < S.range_limits[k]) ||
+                                  (slab(q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, r.o, inv_w, tmin_w) && !(tmin_w > lw_cut));
+                if (!pass) continue;
+                const uint32_t left = __float_as_uint(q0.w);
+                if (left & 0x80000000u) {
+                    if (left == 0xFFFFFFFFu) continue;
+                    const uint32_t idx = atomicAdd(&out_n, 1u);
+                    uint32_t slot = RT_REF_NONE;
+                    if (idx < F.seg_items) slot = blockIdx.x * F.seg_items + idx;
+                    else {
+                        const uint32_t j = atomicAdd(&F.item_counts[F.n_seg - 1], 1u);      // the shared overflow segment
+                        if (j < F.ovf_items) slot = (F.n_seg - 1) * F.seg_items + j;
+                        else *F.overflow = 1u;
+                    }
+                    if (slot != RT_REF_NONE) F.items[slot] = make_uint2(gi, left & 0x7FFFFFFFu);
+                } else {
+                    walk[sp++ * blockDim.x] = __float_as_uint(q1.w);
+                    walk[sp++ * blockDim.x] = left;
+                }
+            }
+        }
+        // Otherwise eight instances at a time: all the tests first, then one reservation in this block's list segment
+        // for the whole group.  Within the group the pairs of instance k come before those of instance k + 1, so a
         // ray's pairs keep the instances' Vec order.
         const unsigned long long lanes_below = (1ull << lane) - 1ull;
-        for (uint32_t g0 = 0; g0 < S.n_instances; g0 += 8) {
+        for (uint32_t g0 = 0; g0 < (S.n_range_nodes ? 0u : S.n_instances); g0 += 8) {
             unsigned long long wants[8];
             uint32_t group_total = 0;
 #pragma unroll
@@ -1684,8 +1714,8 @@ extern "C" hipError_t rt_launch_level(const DScene* S, const DFrame* F, uint32_t
     if (stop && level > (uint32_t)atoi(stop)) return hipSuccess;
 #endif
     if (marks) (void)hipEventRecord(marks[0], stream);
-    hipLaunchKernelGGL(rt_setup, dim3(blocks), dim3(RT_SETUP_THREADS), lds + analytic_stage_words(*S) * sizeof(uint32_t), stream, *S,
-                       *F, level);
+    hipLaunchKernelGGL(rt_setup, dim3(blocks), dim3(RT_SETUP_THREADS),
+                       lds + (analytic_stage_words(*S) + (size_t)S->range_depth * RT_SETUP_THREADS) * sizeof(uint32_t), stream, *S, *F, level);
     hipLaunchKernelGGL(rt_setup_slow, dim3(blocks), dim3(RT_BLOCK_THREADS), lds + analytic_stage_words(*S) * sizeof(uint32_t), stream,
                        *S, *F, level);
     if (marks) (void)hipEventRecord(marks[1], stream);
