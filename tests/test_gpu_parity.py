@@ -289,3 +289,16 @@ def test_random_scenes(tmp_path_factory, block):
             assert_parity(got, want, min_within_1=0.995)
         except AssertionError as e:
             raise AssertionError("seed %d: %s" % (seed, e))
+
+
+def test_degenerate_instance_takes_the_exact_path(tmp_path_factory):
+    """An instance scaled to zero along one axis: its inverse matrices are what glm::inverse makes of a singular
+    matrix, no culling box can be trusted, and the local rays have NaN directions.  Every ray then goes through
+    the kernel that follows the reference's own evaluation order - and must still agree with the oracle."""
+    from rust_raytracer_amd import synthetic
+    d = str(tmp_path_factory.mktemp("degenerate_models"))
+    scene = json.loads(synthetic.instance_grid_scene(d, 3, 2, 2, 160, 90))
+    scene["mesh_instances"][4]["scale"] = {"x": 0.0, "y": 1.0, "z": 1.0}
+    s = orc.OracleScene.from_text(json.dumps(scene), d)
+    got, want = render_both(s, max_depth=5)
+    assert_parity(got, want, min_within_1=0.995)
