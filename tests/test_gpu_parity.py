@@ -1,6 +1,6 @@
 """HIP renderer (through the C ABI) against the CPU oracle on the same scene arrays.
 
-Bar (BASELINE.json north_star): primary hit primitive / instance ids and the shadow / reflection /
+Bar: primary hit primitive / instance ids and the shadow / reflection /
 refraction flags bit-exact for every pixel; RGB8 within 1 LSB on >= 99.9 % of the pixels.  The
 colour tolerance exists because the device sums throughput-weighted contributions where the
 reference evaluates the recursion bottom-up (a last-bit difference before quantisation) and because
