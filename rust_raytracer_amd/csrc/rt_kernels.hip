@@ -1240,11 +1240,12 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
                 const float dx = __shfl(lr.d.x, src), dy = __shfl(lr.d.y, src), dz = __shfl(lr.d.z, src);
                 const float s_limit = __shfl(limit, src), s_prune = __shfl(prune_abs, src), s_thr = __shfl(shadow_thr, src);
                 const float s_idn = __shfl(inv_dn, src);
+                const float ix = __shfl(inv.x, src), iy = __shfl(inv.y, src), iz = __shfl(inv.z, src);
                 const uint32_t s_item = __shfl(item, src), s_gi = __shfl(gi, src), s_ii = __shfl(ii, src);
                 const uint32_t s_owner = __shfl(owner, src), s_base = __shfl(base, src);
                 if (taking) {                                                  // only `fast` walks are shared
                     lr.o = mk(ox, oy, oz); lr.d = mk(dx, dy, dz);
-                    inv = mk(1.0f / lr.d.x, 1.0f / lr.d.y, 1.0f / lr.d.z);
+                    inv = mk(ix, iy, iz);
                     limit = s_limit; prune_abs = s_prune; shadow_thr = s_thr; inv_dn = s_idn;
                     item = s_item; gi = s_gi; ii = s_ii; owner = s_owner;
                     fast = true;
@@ -1716,7 +1717,10 @@ extern "C" hipError_t rt_launch_level(const DScene* S, const DFrame* F, uint32_t
     if (marks) (void)hipEventRecord(marks[0], stream);
     hipLaunchKernelGGL(rt_setup, dim3(blocks), dim3(RT_SETUP_THREADS),
                        lds + (analytic_stage_words(*S) + (size_t)S->range_depth * RT_SETUP_THREADS) * sizeof(uint32_t), stream, *S, *F, level);
-    hipLaunchKernelGGL(rt_setup_slow, dim3(blocks), dim3(RT_BLOCK_THREADS), lds + analytic_stage_words(*S) * sizeof(uint32_t), stream,
+    // In a scene whose instances all have culling boxes only stray rays (NaN components) reach this kernel, if any:
+    // a small grid keeps the usual empty launch cheap.  (Block b continues list segment b, so any grid <= blocks works.)
+    const uint32_t slow_blocks = (S->all_cullable && blocks > 64) ? 64 : blocks;
+    hipLaunchKernelGGL(rt_setup_slow, dim3(slow_blocks), dim3(RT_BLOCK_THREADS), lds + analytic_stage_words(*S) * sizeof(uint32_t), stream,
                        *S, *F, level);
     if (marks) (void)hipEventRecord(marks[1], stream);
     if (S->n_instances > 0)
