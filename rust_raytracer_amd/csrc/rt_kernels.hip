@@ -1382,6 +1382,9 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
 // (raytracer.rs:65-135), except the Phong sum, which has to wait for its shadow rays (kernel D).
 // Shadow rays only record their verdict (raytracer.rs:171-187).
 // ======================================================================================================
+// five waves per SIMD: the kernel needs 97 registers, which the allocation granule would round up to four waves'
+// worth; the list kernels run five blocks per compute unit
+__attribute__((amdgpu_waves_per_eu(5, 5)))
 __global__ void __launch_bounds__(RT_SHADE_THREADS) rt_shade(const DScene S, const DFrame F, const uint32_t level) {
     extern __shared__ uint32_t lds[];
     uint32_t* pre = lds;
