@@ -533,7 +533,8 @@ static int ensure_frame(RtScene* s, const Geometry& g, uint32_t max_depth, bool 
         const size_t item_slots = (size_t)blocks * f.seg_items + f.ovf_items;
         const size_t fat_slots = (size_t)blocks * f.seg_fat + f.ovf_fat;
         const size_t hit_slots = (size_t)blocks * f.seg_hits + f.ovf_hits;
-        const size_t flag_bytes = hit_slots * (s->d.n_lights ? s->d.n_lights : 1);
+        const size_t all_ray_slots = ray_slots + hit_slots * s->d.n_lights;      // + the shadow rays, see DFrame::rays
+        if (all_ray_slots >= RT_META_RAY_LIMIT) return fail(RT_ERR_OUT_OF_RANGE, "a frame needs more than 2^31 ray slots per depth");
         s->stats_words = (size_t)blocks * 4 * 8;
         int rc;
         // colour sums and poison words in one allocation, all counters in another: two clears per frame
@@ -543,13 +544,13 @@ static int ensure_frame(RtScene* s, const Geometry& g, uint32_t max_depth, bool 
         s->counter_words = 7 * (size_t)f.n_seg + 2 * (RT_MAX_DEPTH_LIMIT + 2) + s->stats_words;
         if ((rc = frame_alloc(s, s->pixel_clear_bytes / sizeof(long long) + 1, &pixels)) ||
             (rc = frame_alloc(s, s->counter_words, &counters)) || (rc = frame_alloc(s, (size_t)3 * g.n_pixels, &f.acc_big)) ||
-            (rc = frame_alloc(s, 2 * ray_slots, &f.rays[0])) || (rc = frame_alloc(s, 2 * ray_slots, &f.rays[1])) ||
-            (rc = frame_alloc(s, ray_slots, &f.best)) ||
+            (rc = frame_alloc(s, 2 * all_ray_slots, &f.rays[0])) || (rc = frame_alloc(s, 2 * all_ray_slots, &f.rays[1])) ||
+            (rc = frame_alloc(s, all_ray_slots, &f.best)) ||
             (rc = frame_alloc(s, item_slots, &f.items)) || (rc = frame_alloc(s, item_slots, &f.item_results)) ||
             (rc = frame_alloc(s, 4 * fat_slots, &f.fat_items)) || (rc = frame_alloc(s, ray_slots, &f.slow_rays)) ||
-            (rc = frame_alloc(s, 3 * hit_slots, &f.hits[0])) || (rc = frame_alloc(s, 3 * hit_slots, &f.hits[1])) ||
-            (rc = frame_alloc(s, flag_bytes, &f.shadow_flags[0])) || (rc = frame_alloc(s, flag_bytes, &f.shadow_flags[1])))
+            (rc = frame_alloc(s, 3 * hit_slots, &f.hits[0])) || (rc = frame_alloc(s, 3 * hit_slots, &f.hits[1])))
             return rc;
+        f.shadow_base = (uint32_t)ray_slots;
         HIP_TRY(hipMemset(f.acc_big, 0, (size_t)3 * g.n_pixels * sizeof(double)));     // rt_resolve keeps it zero afterwards
         f.acc = pixels;
         f.poison = reinterpret_cast<unsigned int*>(pixels + (size_t)3 * g.n_pixels);
@@ -762,7 +763,7 @@ extern "C" int rt_last_kernel_ms(RtScene* s, float out_ms[RT_N_LEVEL_KERNELS], u
     for (uint32_t level = 0; level < s->marked_levels; ++level) {
         const hipEvent_t* m = &s->marks[(RT_N_LEVEL_KERNELS + 1) * (size_t)level];
         for (int k = 0; k < RT_N_LEVEL_KERNELS; ++k) {
-            const bool launched = k == RT_KERNEL_SETUP || k == RT_KERNEL_SHADE ||
+            const bool launched = k == RT_KERNEL_SETUP || (k == RT_KERNEL_SHADE && level < s->f.max_depth) ||
                                   ((k == RT_KERNEL_TRAVERSE || k == RT_KERNEL_ROOT) && s->d.n_instances > 0) ||
                                   (k == RT_KERNEL_PHONG && level > 0 && s->d.n_lights > 0);
             if (!launched) continue;

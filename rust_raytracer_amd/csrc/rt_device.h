@@ -22,6 +22,7 @@ struct float4 { float x, y, z, w; };
 
 #define RT_MAX_DEPTH_LIMIT 63      // depth is carried in 6 bits of a ray record
 #define RT_MAX_PIXELS_PER_SHARD (1u << 25)
+#define RT_META_RAY_LIMIT 0x7FFFFFFFull   // ray slots are 31-bit numbers
 
 struct DLight {
     float pos[4];          // RtLight::position
@@ -137,7 +138,12 @@ struct DFrame {
     unsigned int* aux_flags;         // [n_pixels] or null
     unsigned int* aux_prim;          // [n_pixels] or null
     unsigned int* aux_inst;          // [n_pixels] or null
-    float4* rays[2];                 // ray records of the current / next depth, 2 float4 each
+    // Ray records of the current / next depth, 2 float4 each.  Slots below shadow_base form the segmented list
+    // of the primary / reflected / transmitted rays; the shadow ray of hit record h towards light l has the fixed
+    // slot shadow_base + h * n_lights + l (raytracer.rs:77-79: one per light per Phong-shaded hit), so the shadow
+    // rays of a depth are enumerated through the hit list and nobody has to append or look them up.
+    float4* rays[2];
+    uint32_t shadow_base;
     unsigned int* ray_counts[2];     // [n_seg]
     unsigned long long* best;        // [ray slots] closest candidate so far: t bits << 32 | order, see rt_kernels.hip
     uint2* items;                    // BVH work items: (ray slot, instance | flags)
@@ -151,7 +157,6 @@ struct DFrame {
     unsigned int* chunk_counter;     // [RT_MAX_DEPTH_LIMIT + 2] input chunks of the BVH walk handed out so far, per depth
     float4* hits[2];                 // Phong-shaded hits waiting for their shadow rays, 3 float4 each
     unsigned int* hit_counts[2];     // [n_seg]
-    unsigned char* shadow_flags[2];  // [hit slots][n_lights]
     unsigned int* wave_stats;        // [waves][8]: rays, primary, shadow, reflected, transmitted
     unsigned int* overflow;          // set to 1 when a list did not fit (the frame is then invalid)
 };

@@ -682,9 +682,12 @@ __global__ void __launch_bounds__(RT_SETUP_THREADS) rt_setup(const DScene S, con
     const unsigned long long ts_begin = clock64();
 #endif
     const uint32_t n_rays = build_prefix(F.ray_counts[p], F.n_seg, F.seg_rays, F.ovf_rays, pre, scratch);
+    // second table: the hit records of the depth above, whose shadow rays are traced at this depth
+    uint32_t* pre_hits = lds + F.n_seg + 1 + blockDim.x;
+    const uint32_t n_hits = build_prefix(F.hit_counts[p ^ 1], F.n_seg, F.seg_hits, F.ovf_hits, pre_hits, scratch);
     // the analytic primitives are staged in LDS (every lane reads the same one: a broadcast, no scalar-load
     // round trip per primitive)
-    uint32_t* stage = lds + F.n_seg + 1 + blockDim.x;
+    uint32_t* stage = pre_hits + F.n_seg + 1;
     const uint32_t stage_words = analytic_stage_words(S);
     const bool staged = stage_words != 0;
     const uint32_t plane_words = S.n_planes * (sizeof(DPlane) / 4), sphere_words = S.n_spheres * (sizeof(DSphere) / 4);
@@ -709,9 +712,12 @@ __global__ void __launch_bounds__(RT_SETUP_THREADS) rt_setup(const DScene S, con
     const uint32_t gwave = (blockIdx.x * blockDim.x + threadIdx.x) / RT_WAVE;
     const uint32_t n_waves = gridDim.x * (blockDim.x / RT_WAVE);
 
-    for (uint32_t c = gwave; (unsigned long long)c * RT_WAVE < n_rays; c += n_waves) {
-        const uint32_t v = c * RT_WAVE + lane;
-        bool active = v < n_rays;
+    // Chunks of 64 rays: first the listed rays, then, light by light, the shadow rays of the hit records (a chunk
+    // never mixes the two kinds, nor two lights).
+    const uint32_t main_chunks = (n_rays + RT_WAVE - 1) / RT_WAVE, hit_chunks = (n_hits + RT_WAVE - 1) / RT_WAVE;
+    const uint32_t all_chunks = main_chunks + S.n_lights * hit_chunks;
+    for (uint32_t c = gwave; c < all_chunks; c += n_waves) {
+        bool active;
         uint32_t gi = 0;
         RayRec rr;
         rr.ray.o = rr.ray.d = mk(0, 0, 0);
@@ -721,10 +727,17 @@ __global__ void __launch_bounds__(RT_SETUP_THREADS) rt_setup(const DScene S, con
         const unsigned long long tc0 = clock64();
         ts[2] += 1;
 #endif
-        {
+        if (c < main_chunks) {
             const uint32_t at = locate_chunk(pre, F.n_seg, F.seg_rays, c * RT_WAVE, n_rays, lane);
-            if (active) { gi = at; rr = load_rec(rays, gi); }
+            active = c * RT_WAVE + lane < n_rays;
+            if (active) gi = at;
+        } else {
+            const uint32_t cs = c - main_chunks, light = cs / hit_chunks, first = (cs - light * hit_chunks) * RT_WAVE;
+            const uint32_t hs = locate_chunk(pre_hits, F.n_seg, F.seg_hits, first, n_hits, lane);
+            active = first + lane < n_hits;
+            if (active) gi = F.shadow_base + hs * S.n_lights + light;
         }
+        if (active) rr = load_rec(rays, gi);
         const Ray r = rr.ray;
         const ShadowSpec ss = shadow_spec(S, rr);
 #ifdef RT_STATS
@@ -1432,15 +1445,9 @@ __global__ void __launch_bounds__(RT_SHADE_THREADS) rt_shade(const DScene S, con
         hit.material = 0;
         const uint32_t pixel = cur.meta & RT_META_PIXEL_MASK;
 
-        if (active && (cur.meta & RT_RAY_SHADOW)) {
-            // ---- shadow ray: raytracer.rs:171-187 --------------------------------------------------------
-            ++n_shadow;
-            const ShadowSpec ss = shadow_spec(S, cur);
-            const bool is_shadow = have && (ss.directional || best_t < ss.limit_world);
-            const uint32_t hit_slot = __float_as_uint(cur.throughput);
-            F.shadow_flags[q][(size_t)hit_slot * S.n_lights + (cur.meta & 0xFFu)] = is_shadow ? 1 : 0;
-        } else if (active) {
-            // ---- primary / reflected / transmitted ray -----------------------------------------------------
+        if (active) {
+            // ---- primary / reflected / transmitted ray (shadow rays are not in this list; rt_phong reads their
+            // closest candidates itself) ----------------------------------------------------------------------
             const uint32_t kind = (cur.meta >> RT_META_KIND_SHIFT) & 1u;
             if (level == 0) ++n_primary; else if (kind) ++n_transmitted; else ++n_reflected;
             if (!have) {
@@ -1524,21 +1531,18 @@ __global__ void __launch_bounds__(RT_SHADE_THREADS) rt_shade(const DScene S, con
             H[1] = make_float4(hit.hit_normal.x, hit.hit_normal.y, hit.hit_normal.z, cur.throughput);
             H[2] = make_float4(-cur.ray.d.x, -cur.ray.d.y, -cur.ray.d.z, __uint_as_float(pixel | (level == 0 ? RT_HIT_DEPTH0 : 0u)));
         }
-        for (uint32_t li = 0; li < S.n_lights; ++li) {
-            const bool want = hit_slot != RT_REF_NONE;
-            const uint32_t slot = append_slot(want, &out_rays, F.seg_rays, F.n_seg, F.ray_counts[q], F.ovf_rays, F.overflow, lane);
-            if (slot != RT_REF_NONE) {
+        if (hit_slot != RT_REF_NONE) {
+            for (uint32_t li = 0; li < S.n_lights; ++li) {
                 const DLight& L = S.lights[li];
                 const bool directional = L.pos[3] == 0.0f;
                 V3 dir = directional ? mk(L.pos[0], L.pos[1], L.pos[2]) : ld3(L.world) - hit.position;      // raytracer.rs:158-167
                 RayRec sr;
                 sr.ray.o = hit.position;
                 sr.ray.d = normalize3(dir);
-                sr.throughput = __uint_as_float(hit_slot);
+                sr.throughput = 0.0f;
                 sr.meta = RT_RAY_SHADOW | li;
-                store_rec(rays_out, slot, sr);
-            } else if (want) {
-                F.shadow_flags[p][(size_t)hit_slot * S.n_lights + li] = 0;                 // list overflow: frame is redone
+                store_rec(rays_out, F.shadow_base + hit_slot * S.n_lights + li, sr);      // its fixed slot, see DFrame::rays
+                ++n_shadow;
             }
         }
         {
@@ -1594,9 +1598,12 @@ __global__ void __launch_bounds__(RT_PHONG_THREADS) rt_phong(const DScene S, con
         uint32_t shadow_bits = 0;
         for (uint32_t li = 0; li < S.n_lights; ++li) {
             const DLight& L = S.lights[li];
-            const bool is_shadow = F.shadow_flags[q][(size_t)hs * S.n_lights + li] != 0;
-            if (is_shadow && li < 4) shadow_bits |= RT_FLAG_SHADOW_LIGHT0 << li;
             const bool directional = L.pos[3] == 0.0f;
+            // trace_shadow_ray, raytracer.rs:171-187: any hit towards a directional light, a hit closer than a point light
+            const unsigned long long key = F.best[F.shadow_base + hs * S.n_lights + li];
+            const bool is_shadow = key != RT_KEY_NONE &&
+                                   (directional || __uint_as_float((uint32_t)(key >> 32)) < distance3(position, ld3(L.world)));
+            if (is_shadow && li < 4) shadow_bits |= RT_FLAG_SHADOW_LIGHT0 << li;
             V3 l = normalize3(directional ? mk(L.pos[0], L.pos[1], L.pos[2]) : ld3(L.world) - position);   // raytracer.rs:209-220
             V3 rv = reflected_dir(l, n);
             float l_dot_n = fmaxf(dot3(l, n), 0.0f);
@@ -1719,7 +1726,8 @@ extern "C" hipError_t rt_launch_level(const DScene* S, const DFrame* F, uint32_t
 #endif
     if (marks) (void)hipEventRecord(marks[0], stream);
     hipLaunchKernelGGL(rt_setup, dim3(blocks), dim3(RT_SETUP_THREADS),
-                       lds + (analytic_stage_words(*S) + (size_t)S->range_depth * RT_SETUP_THREADS) * sizeof(uint32_t), stream, *S, *F, level);
+                       lds + (F->n_seg + 1 + analytic_stage_words(*S) + (size_t)S->range_depth * RT_SETUP_THREADS) * sizeof(uint32_t),
+                       stream, *S, *F, level);
     // In a scene whose instances all have culling boxes only stray rays (NaN components) reach this kernel, if any:
     // a small grid keeps the usual empty launch cheap.  (Block b continues list segment b, so any grid <= blocks works.)
     const uint32_t slow_blocks = (S->all_cullable && blocks > 64) ? 64 : blocks;
@@ -1736,7 +1744,9 @@ extern "C" hipError_t rt_launch_level(const DScene* S, const DFrame* F, uint32_t
     if (stop && level == (uint32_t)atoi(stop)) return hipGetLastError();
 #endif
     if (marks) (void)hipEventRecord(marks[3], stream);
-    hipLaunchKernelGGL(rt_shade, dim3(blocks), dim3(RT_SHADE_THREADS), lds, stream, *S, *F, level);
+    // depth max_depth only exists for the shadow rays of the deepest hits: no listed rays, nothing to shade
+    if (level < F->max_depth)
+        hipLaunchKernelGGL(rt_shade, dim3(blocks), dim3(RT_SHADE_THREADS), lds, stream, *S, *F, level);
     if (marks) (void)hipEventRecord(marks[4], stream);
     if (level > 0 && S->n_lights > 0)
         hipLaunchKernelGGL(rt_phong, dim3(blocks), dim3(RT_PHONG_THREADS), lds, stream, *S, *F, level);
