@@ -40,7 +40,7 @@ WORKLOADS = {
 #   flops = 27*aabb_tests + 57*(mesh_triangle_tests + triangle_tests) + 40*sphere_tests + 14*plane_tests
 #           + 90*instance_transforms + 60*light_shades
 # The BVH walk kernel (rt_traverse) owns the aabb_tests and mesh_triangle_tests terms; the instance
-# transforms and analytic primitives belong to rt_setup, normals and light sums to rt_shade / rt_phong.
+# transforms and analytic primitives belong to rt_setup, normals and light sums to rt_shade.
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E
 FP32_NO_FMA_PEAK_TFLOPS = 78.6   # 157.3 TFLOP/s vector FP32 counts an FMA as two; contraction is forbidden here
 

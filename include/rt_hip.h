@@ -259,9 +259,9 @@ int rt_last_trace_ms(RtScene* scene, float* out_ms);
 
 /* The kernels launched per recursion depth: analytic primitives and instance culling, local rays and root
  * boxes of the surviving (ray, instance) pairs (intersect.rs:296-308), BVH walk (intersect.rs:228-269),
- * shading of the closest hits (raytracer.rs:65-135), Phong sum once the shadow rays are known
- * (raytracer.rs:137-187). */
-enum { RT_KERNEL_SETUP = 0, RT_KERNEL_ROOT, RT_KERNEL_TRAVERSE, RT_KERNEL_SHADE, RT_KERNEL_PHONG, RT_N_LEVEL_KERNELS };
+ * shading of the closest hits (raytracer.rs:65-135) together with the Phong sums of the depth above, whose
+ * shadow rays are known by then (raytracer.rs:137-187). */
+enum { RT_KERNEL_SETUP = 0, RT_KERNEL_ROOT, RT_KERNEL_TRAVERSE, RT_KERNEL_SHADE, RT_N_LEVEL_KERNELS };
 
 /* Kernel timing mode (off by default): every launch of the per-depth kernels is bracketed by HIP
  * events on the launch stream.  No counterpart in the reference (its only timing is native_app's

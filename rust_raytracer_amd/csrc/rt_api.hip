@@ -74,7 +74,7 @@ struct RtScene {
     uint32_t debug_queue_capacity = 0;
     size_t stats_words = 0;
     size_t pixel_clear_bytes = 0, counter_words = 0;
-    // kernel timing mode (rt_set_kernel_timing): six events per recursion depth
+    // kernel timing mode (rt_set_kernel_timing): RT_N_LEVEL_KERNELS + 1 events per recursion depth
     bool kernel_timing = false;
     std::vector<hipEvent_t> marks;
     uint32_t marked_levels = 0;         // depths of the last frame that carry marks
@@ -763,9 +763,8 @@ extern "C" int rt_last_kernel_ms(RtScene* s, float out_ms[RT_N_LEVEL_KERNELS], u
     for (uint32_t level = 0; level < s->marked_levels; ++level) {
         const hipEvent_t* m = &s->marks[(RT_N_LEVEL_KERNELS + 1) * (size_t)level];
         for (int k = 0; k < RT_N_LEVEL_KERNELS; ++k) {
-            const bool launched = k == RT_KERNEL_SETUP || (k == RT_KERNEL_SHADE && level < s->f.max_depth) ||
-                                  ((k == RT_KERNEL_TRAVERSE || k == RT_KERNEL_ROOT) && s->d.n_instances > 0) ||
-                                  (k == RT_KERNEL_PHONG && level > 0 && s->d.n_lights > 0);
+            const bool launched = k == RT_KERNEL_SETUP || k == RT_KERNEL_SHADE ||
+                                  ((k == RT_KERNEL_TRAVERSE || k == RT_KERNEL_ROOT) && s->d.n_instances > 0);
             if (!launched) continue;
             float ms = 0.0f;
             HIP_TRY(hipEventElapsedTime(&ms, m[k], m[k + 1]));

@@ -19,8 +19,8 @@
 //      A2  rt_root        per pair: the mesh-local ray and the exact root-box test -> 64-byte walk item
 //      B   rt_traverse    BVH walk, one walk item per lane, lanes refilled as they finish - every lane
 //                         that is busy is busy with the same code
-//      C   rt_shade       closest hit -> hit point, material, child rays and shadow rays
-//      D   rt_phong       Phong sums of the previous depth's hits once their shadow rays are back
+//      C   rt_shade       closest hit -> hit point, material, child rays and shadow rays; then the Phong sums
+//                         of the previous depth's hits, whose shadow rays were traced at this depth
 //    Splitting by kind of work is what keeps the 64 lanes of a wave busy: in a one-kernel version
 //    fewer than 5 % of the lanes had a BVH node to visit in a given round.
 //  * Lists are appended to without device-wide atomics (about 10 ns each when contended, all
@@ -47,9 +47,6 @@
 #endif
 #ifndef RT_SHADE_THREADS
 #define RT_SHADE_THREADS 256
-#endif
-#ifndef RT_PHONG_THREADS
-#define RT_PHONG_THREADS 256
 #endif
 #define RT_MAX_LIST_THREADS 512
 #define RT_WAVE 64
@@ -1391,6 +1388,53 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
 }
 
 // ======================================================================================================
+// Second half of kernel C: the Phong sum of shade_phong / radiance (raytracer.rs:75-84, 137-153) for the hits
+// of the previous depth, now that their shadow rays have been traced.  Block-wide (it builds a prefix table).
+// ======================================================================================================
+__device__ void phong_pass(const DScene& S, const DFrame& F, const uint32_t level, uint32_t* pre, uint32_t* scratch) {
+    const uint32_t q = (level & 1) ^ 1;            // parity of the depth whose hits are finished here
+    const uint32_t n_hits = build_prefix(F.hit_counts[q], F.n_seg, F.seg_hits, F.ovf_hits, pre, scratch);
+    const uint32_t lane = threadIdx.x & (RT_WAVE - 1);
+    const uint32_t gwave = (blockIdx.x * blockDim.x + threadIdx.x) / RT_WAVE;
+    const uint32_t n_waves = gridDim.x * (blockDim.x / RT_WAVE);
+    for (uint32_t c = gwave; (unsigned long long)c * RT_WAVE < n_hits; c += n_waves) {
+        const uint32_t v = c * RT_WAVE + lane;
+        const uint32_t hs = locate_chunk(pre, F.n_seg, F.seg_hits, c * RT_WAVE, n_hits, lane);
+        if (v >= n_hits) continue;
+        const float4* H = F.hits[q] + 3 * (size_t)hs;
+        const float4 h0 = H[0], h1 = H[1], h2 = H[2];
+        const V3 position = mk(h0.x, h0.y, h0.z), n = mk(h1.x, h1.y, h1.z), view = mk(h2.x, h2.y, h2.z);
+        const RtMaterial& mat = S.materials[__float_as_uint(h0.w)];
+        const float throughput = h1.w;
+        const uint32_t pw = __float_as_uint(h2.w), pixel = pw & RT_META_PIXEL_MASK;
+        V3 color = mk(0, 0, 0);
+        uint32_t shadow_bits = 0;
+        for (uint32_t li = 0; li < S.n_lights; ++li) {
+            const DLight& L = S.lights[li];
+            const bool directional = L.pos[3] == 0.0f;
+            // trace_shadow_ray, raytracer.rs:171-187: any hit towards a directional light, a hit closer than a point light
+            const unsigned long long key = F.best[F.shadow_base + hs * S.n_lights + li];
+            const bool is_shadow = key != RT_KEY_NONE &&
+                                   (directional || __uint_as_float((uint32_t)(key >> 32)) < distance3(position, ld3(L.world)));
+            if (is_shadow && li < 4) shadow_bits |= RT_FLAG_SHADOW_LIGHT0 << li;
+            V3 l = normalize3(directional ? mk(L.pos[0], L.pos[1], L.pos[2]) : ld3(L.world) - position);   // raytracer.rs:209-220
+            V3 rv = reflected_dir(l, n);
+            float l_dot_n = fmaxf(dot3(l, n), 0.0f);
+            float r_dot_v = fmaxf(dot3(rv, view), 0.0f);
+            V3 emissive = ld3(mat.emissive);
+            V3 ambient = cmul(ld3(L.ambient), ld3(mat.ambient));
+            V3 zero = mk(0.0f, 0.0f, 0.0f);
+            V3 diffuse = is_shadow ? zero : cmul(ld3(L.diffuse), ld3(mat.diffuse)) * l_dot_n;
+            V3 specular = is_shadow ? zero : cmul(ld3(L.specular), ld3(mat.specular)) * powf(r_dot_v, mat.shininess);
+            V3 rad = emissive + ambient + diffuse + specular;
+            color = (li == 0) ? rad : color + rad;                     // color::add_option
+        }
+        add_color(F, pixel, color * throughput);
+        if (F.aux_flags && (pw & RT_HIT_DEPTH0) && shadow_bits) atomicOr(F.aux_flags + pixel, shadow_bits);
+    }
+}
+
+// ======================================================================================================
 // Kernel C: per ray of this depth, what raytrace_impl / shade do once the closest hit is known
 // (raytracer.rs:65-135), except the Phong sum, which has to wait for its shadow rays (kernel D).
 // Shadow rays only record their verdict (raytracer.rs:171-187).
@@ -1446,7 +1490,7 @@ __global__ void __launch_bounds__(RT_SHADE_THREADS) rt_shade(const DScene S, con
         const uint32_t pixel = cur.meta & RT_META_PIXEL_MASK;
 
         if (active) {
-            // ---- primary / reflected / transmitted ray (shadow rays are not in this list; rt_phong reads their
+            // ---- primary / reflected / transmitted ray (shadow rays are not in this list; phong_pass reads their
             // closest candidates itself) ----------------------------------------------------------------------
             const uint32_t kind = (cur.meta >> RT_META_KIND_SHIFT) & 1u;
             if (level == 0) ++n_primary; else if (kind) ++n_transmitted; else ++n_reflected;
@@ -1569,56 +1613,8 @@ __global__ void __launch_bounds__(RT_SHADE_THREADS) rt_shade(const DScene S, con
         F.ray_counts[q][blockIdx.x] = out_rays < F.seg_rays ? out_rays : F.seg_rays;
         F.hit_counts[p][blockIdx.x] = out_hits < F.seg_hits ? out_hits : F.seg_hits;
     }
-}
-
-// ======================================================================================================
-// Kernel D: the Phong sum of shade_phong / radiance (raytracer.rs:75-84, 137-153) for the hits of the
-// previous depth, now that their shadow rays have been traced.
-// ======================================================================================================
-__global__ void __launch_bounds__(RT_PHONG_THREADS) rt_phong(const DScene S, const DFrame F, const uint32_t level) {
-    extern __shared__ uint32_t lds[];
-    uint32_t* pre = lds;
-    uint32_t* scratch = lds + F.n_seg + 1;
-    const uint32_t q = (level & 1) ^ 1;            // parity of the depth whose hits are finished here
-    const uint32_t n_hits = build_prefix(F.hit_counts[q], F.n_seg, F.seg_hits, F.ovf_hits, pre, scratch);
-    const uint32_t lane = threadIdx.x & (RT_WAVE - 1);
-    const uint32_t gwave = (blockIdx.x * blockDim.x + threadIdx.x) / RT_WAVE;
-    const uint32_t n_waves = gridDim.x * (blockDim.x / RT_WAVE);
-    for (uint32_t c = gwave; (unsigned long long)c * RT_WAVE < n_hits; c += n_waves) {
-        const uint32_t v = c * RT_WAVE + lane;
-        const uint32_t hs = locate_chunk(pre, F.n_seg, F.seg_hits, c * RT_WAVE, n_hits, lane);
-        if (v >= n_hits) continue;
-        const float4* H = F.hits[q] + 3 * (size_t)hs;
-        const float4 h0 = H[0], h1 = H[1], h2 = H[2];
-        const V3 position = mk(h0.x, h0.y, h0.z), n = mk(h1.x, h1.y, h1.z), view = mk(h2.x, h2.y, h2.z);
-        const RtMaterial& mat = S.materials[__float_as_uint(h0.w)];
-        const float throughput = h1.w;
-        const uint32_t pw = __float_as_uint(h2.w), pixel = pw & RT_META_PIXEL_MASK;
-        V3 color = mk(0, 0, 0);
-        uint32_t shadow_bits = 0;
-        for (uint32_t li = 0; li < S.n_lights; ++li) {
-            const DLight& L = S.lights[li];
-            const bool directional = L.pos[3] == 0.0f;
-            // trace_shadow_ray, raytracer.rs:171-187: any hit towards a directional light, a hit closer than a point light
-            const unsigned long long key = F.best[F.shadow_base + hs * S.n_lights + li];
-            const bool is_shadow = key != RT_KEY_NONE &&
-                                   (directional || __uint_as_float((uint32_t)(key >> 32)) < distance3(position, ld3(L.world)));
-            if (is_shadow && li < 4) shadow_bits |= RT_FLAG_SHADOW_LIGHT0 << li;
-            V3 l = normalize3(directional ? mk(L.pos[0], L.pos[1], L.pos[2]) : ld3(L.world) - position);   // raytracer.rs:209-220
-            V3 rv = reflected_dir(l, n);
-            float l_dot_n = fmaxf(dot3(l, n), 0.0f);
-            float r_dot_v = fmaxf(dot3(rv, view), 0.0f);
-            V3 emissive = ld3(mat.emissive);
-            V3 ambient = cmul(ld3(L.ambient), ld3(mat.ambient));
-            V3 zero = mk(0.0f, 0.0f, 0.0f);
-            V3 diffuse = is_shadow ? zero : cmul(ld3(L.diffuse), ld3(mat.diffuse)) * l_dot_n;
-            V3 specular = is_shadow ? zero : cmul(ld3(L.specular), ld3(mat.specular)) * powf(r_dot_v, mat.shininess);
-            V3 rad = emissive + ambient + diffuse + specular;
-            color = (li == 0) ? rad : color + rad;                     // color::add_option
-        }
-        add_color(F, pixel, color * throughput);
-        if (F.aux_flags && (pw & RT_HIT_DEPTH0) && shadow_bits) atomicOr(F.aux_flags + pixel, shadow_bits);
-    }
+    // the hits of the depth above are complete now that this depth's rays - their shadow rays among them - are traced
+    if (level > 0 && S.n_lights > 0) phong_pass(S, F, level, pre, scratch);
 }
 
 // color.rs:42-52 + canvas layout.  One thread per local pixel.
@@ -1716,7 +1712,7 @@ extern "C" hipError_t rt_launch_generate(const DFrame* F, uint32_t blocks, hipSt
 
 // One recursion depth: A, B, C and (from depth 1 on) D.  `blocks` is the grid of the list-producing
 // kernels (F->n_seg - 1), `traverse_blocks` that of the BVH walk.
-// `marks`, when not null, are six events recorded before A and after A, A2, B, C and D (kernel timing mode).
+// `marks`, when not null, are five events recorded before A and after A', A2, B and C (kernel timing mode).
 extern "C" hipError_t rt_launch_level(const DScene* S, const DFrame* F, uint32_t level, uint32_t blocks,
                                       uint32_t traverse_blocks, hipStream_t stream, hipEvent_t* marks) {
     const size_t lds = list_lds_bytes(F->n_seg);
@@ -1744,13 +1740,8 @@ extern "C" hipError_t rt_launch_level(const DScene* S, const DFrame* F, uint32_t
     if (stop && level == (uint32_t)atoi(stop)) return hipGetLastError();
 #endif
     if (marks) (void)hipEventRecord(marks[3], stream);
-    // depth max_depth only exists for the shadow rays of the deepest hits: no listed rays, nothing to shade
-    if (level < F->max_depth)
-        hipLaunchKernelGGL(rt_shade, dim3(blocks), dim3(RT_SHADE_THREADS), lds, stream, *S, *F, level);
+    hipLaunchKernelGGL(rt_shade, dim3(blocks), dim3(RT_SHADE_THREADS), lds, stream, *S, *F, level);
     if (marks) (void)hipEventRecord(marks[4], stream);
-    if (level > 0 && S->n_lights > 0)
-        hipLaunchKernelGGL(rt_phong, dim3(blocks), dim3(RT_PHONG_THREADS), lds, stream, *S, *F, level);
-    if (marks) (void)hipEventRecord(marks[5], stream);
     return hipGetLastError();
 }
 

@@ -14,6 +14,6 @@ for r in frame:
     name = r['Kernel_Name'].split('(')[0]
     tot[name] += d
     line.append('%s %.0f' % (name.replace('rt_', ''), d))
-    if name == 'rt_phong' or name == 'rt_generate': print(' | '.join(line)); line = []
+    if name == 'rt_shade' or name == 'rt_generate': print(' | '.join(line)); line = []
 print(' | '.join(line))
 print('span %.1f us' % ((int(frame[-1]['End_Timestamp']) - t0) / 1000.0), {k: round(v, 1) for k, v in tot.items()})
