@@ -1,4 +1,9 @@
 // TEST INFRASTRUCTURE - CPU oracle, not part of the shipped renderer.
+//
+// A restatement of the reference's render path in C++ (the reference is Rust and cannot be built here).  Pinned by
+// the reference's own known answers (the intersection tests of raytracing/intersect_tests.rs, the hull and area
+// tests of bvh/hull.rs and geometry/aabb.rs) and by mesh-free crops of its committed render of og_scene_rust.json;
+// BVH traversal and instance transforms on meshes, for which the reference holds no fixture, are parity unpinned.
 #pragma once
 #include "orc_scene.h"
 
@@ -27,8 +32,9 @@ bool intersect_plane(const RtPlane& p, const Ray& ray, Hitpoint* out);
 bool intersect_triangle(const RtTriangle& t, const Ray& ray, Hitpoint* out);
 bool intersect_aabb(const float bmin[3], const float bmax[3], const Ray& ray);
 // scene.rs:120-140
-void render_depth_map(const Scene& s, int threads, int channels, uint8_t* rgb, uint64_t counters[RT_N_COUNTERS]);
 bool intersect_scene(const Scene& s, const Ray& ray, Hitpoint* out, Counters* ctr);
+// Raytracer::depth_map for every pixel, raytracer.rs:21-28 (misses show the background, main.rs:58-61)
+void render_depth_map(const Scene& s, int threads, int channels, uint8_t* rgb, uint64_t counters[RT_N_COUNTERS]);
 
 struct PixelResult {
     Vec3 color;           // before quantisation
