@@ -302,3 +302,44 @@ def test_degenerate_instance_takes_the_exact_path(tmp_path_factory):
     s = orc.OracleScene.from_text(json.dumps(scene), d)
     got, want = render_both(s, max_depth=5)
     assert_parity(got, want, min_within_1=0.995)
+
+
+def test_api_errors(scenes_dir, model_dir):
+    """Argument validation of the C ABI: error codes with a message instead of the reference's panics."""
+    import ctypes as C
+    s = load(scenes_dir, model_dir, "cornell_box", 64, 48)
+    L = native.lib()
+    dev = native.DeviceScene(s.desc(), 0)
+    try:
+        out = np.zeros((48, 64, 3), dtype=np.uint8)
+        p = abi.RtRenderParams(10, abi.RT_FORMAT_RGB8, 0, 1, 0, 0, None)
+        assert L.rt_render(dev._h, C.byref(p), out.ctypes.data, None) == abi.RT_ERR_INVALID_ARGUMENT     # camera not set
+        assert b"camera" in L.rt_last_error()
+        m, w, h = s.camera()
+        dev.set_camera(m, w, h)
+        for bad in (abi.RtRenderParams(64, abi.RT_FORMAT_RGB8, 0, 1, 0, 0, None),        # max_depth beyond the limit
+                    abi.RtRenderParams(10, 7, 0, 1, 0, 0, None),                         # unknown output format
+                    abi.RtRenderParams(10, abi.RT_FORMAT_RGB8, 0, 1, 5, 0, None),        # unknown mode
+                    abi.RtRenderParams(10, abi.RT_FORMAT_RGB8, 0, 1, 0, 1, None)):       # reserved field used
+            assert L.rt_render(dev._h, C.byref(bad), out.ctypes.data, None) == abi.RT_ERR_INVALID_ARGUMENT
+            assert L.rt_last_error() != b""
+        shard = abi.RtRenderParams(10, abi.RT_FORMAT_RGB8, 3, 3, 0, 0, None)             # shard_index >= shard_count
+        n = C.c_uint64()
+        assert L.rt_shard_bytes(dev._h, C.byref(shard), C.byref(n)) == abi.RT_ERR_INVALID_ARGUMENT
+        assert L.rt_render(dev._h, C.byref(p), None, None) == abi.RT_ERR_INVALID_ARGUMENT               # null canvas
+        assert L.rt_render(dev._h, C.byref(p), out.ctypes.data, None) == 0                                # and it still works
+        assert out.any()
+    finally:
+        dev.close()
+    # a scene whose indices point outside its arrays is refused at creation
+    desc = s.desc()
+    broken = abi.RtSceneDesc.from_buffer_copy(desc)
+    spheres = (abi.RtSphere * desc.n_spheres).from_buffer_copy(C.string_at(desc.spheres, C.sizeof(abi.RtSphere) * desc.n_spheres))
+    spheres[0].material = desc.n_materials + 3
+    broken.spheres = C.cast(spheres, C.POINTER(abi.RtSphere))
+    with pytest.raises(native.RtError) as e:
+        native.DeviceScene(broken, 0)
+    assert e.value.code == abi.RT_ERR_OUT_OF_RANGE
+    with pytest.raises(native.RtError) as e:
+        native.DeviceScene(desc, 99)
+    assert e.value.code == abi.RT_ERR_NO_DEVICE
