@@ -280,7 +280,7 @@ void rt_scene_destroy(RtScene* scene);
  * after rt_render_device the overflow is reported by rt_last_ray_counts, and the next frame gets
  * longer lists. */
 int rt_debug_set_queue_capacity(RtScene* scene, uint32_t capacity);
-int rt_debug_last_spilled(RtScene* scene, uint32_t* out_count);
+int rt_debug_last_regrown(RtScene* scene, uint32_t* out_count);
 
 /* Thread-local, static storage; never NULL. */
 const char* rt_last_error(void);

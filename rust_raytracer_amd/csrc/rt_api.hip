@@ -775,16 +775,16 @@ extern "C" int rt_last_kernel_ms(RtScene* s, float out_ms[RT_N_LEVEL_KERNELS], u
     return RT_OK;
 }
 
-// Debug aid for tests: caps the per-depth ray queue (0 restores the default of four rays per pixel)
-// and reports how many child rays did not fit and were traced by their parent lane instead.
+// Test aids: the first caps the ray lists of a recursion depth (0 restores the default of eight rays per pixel), the
+// second reports how often rt_render had to enlarge the lists and redo its last frame.
 extern "C" int rt_debug_set_queue_capacity(RtScene* s, uint32_t capacity) {
     if (!s) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_set_queue_capacity: null argument");
     s->debug_queue_capacity = capacity;
     return RT_OK;
 }
 
-extern "C" int rt_debug_last_spilled(RtScene* s, uint32_t* out) {
-    if (!s || !out) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_last_spilled: null argument");
+extern "C" int rt_debug_last_regrown(RtScene* s, uint32_t* out) {
+    if (!s || !out) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_last_regrown: null argument");
     if (!s->timed) return fail(RT_ERR_INVALID_ARGUMENT, "nothing has been rendered on this handle yet");
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipStreamSynchronize(s->last_stream));

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "librt_hip.so")
 EXPORTS = ["rt_scene_create", "rt_scene_set_camera", "rt_render", "rt_render_device", "rt_shard_bytes",
            "rt_assemble_shards", "rt_last_ray_counts", "rt_last_render_ms", "rt_last_trace_ms", "rt_set_kernel_timing",
            "rt_last_kernel_ms", "rt_scene_destroy",
-           "rt_debug_set_queue_capacity", "rt_debug_last_spilled", "rt_last_error"]
+           "rt_debug_set_queue_capacity", "rt_debug_last_regrown", "rt_last_error"]
 # every function include/rt_host.h declares
 HOST_EXPORTS = ["rt_host_scene_parse", "rt_host_scene_load", "rt_host_scene_desc", "rt_host_scene_camera",
                 "rt_host_scene_resize_screen", "rt_host_scene_turn_camera", "rt_host_scene_set_camera_pose",
@@ -78,7 +78,7 @@ def lib():
         L.rt_scene_destroy.argtypes = [vp]
         L.rt_scene_destroy.restype = None
         L.rt_debug_set_queue_capacity.argtypes = [vp, u32]
-        L.rt_debug_last_spilled.argtypes = [vp, C.POINTER(u32)]
+        L.rt_debug_last_regrown.argtypes = [vp, C.POINTER(u32)]
         L.rt_last_error.restype = C.c_char_p
         fp = C.POINTER(C.c_float)
         L.rt_host_scene_parse.argtypes = [C.c_char_p, C.c_size_t, MESH_LOAD_FN, vp, C.POINTER(vp)]
@@ -199,9 +199,9 @@ class DeviceScene:
     def debug_set_queue_capacity(self, capacity: int):
         check(lib().rt_debug_set_queue_capacity(self._h, capacity))
 
-    def debug_last_spilled(self) -> int:
+    def debug_last_regrown(self) -> int:
         n = C.c_uint32()
-        check(lib().rt_debug_last_spilled(self._h, C.byref(n)))
+        check(lib().rt_debug_last_regrown(self._h, C.byref(n)))
         return int(n.value)
 
 

@@ -24,4 +24,4 @@ for k in ('flags', 'prim_id', 'instance_id'):
 print('counters', got['counters'][:5].tolist(), want['counters'][:5].tolist())
 d = np.abs(got['rgb'].astype(int) - want['rgb'].astype(int)).max(axis=2)
 print('rgb exact %.6f within1 %.6f max %d' % ((d == 0).mean(), (d <= 1).mean(), d.max()))
-print('spilled', dev.debug_last_spilled())
+print('spilled', dev.debug_last_regrown())

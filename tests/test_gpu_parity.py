@@ -26,7 +26,7 @@ def render_both(oscene, max_depth=10, queue_capacity=0):
         if queue_capacity:
             dev.debug_set_queue_capacity(queue_capacity)
         got = dev.render(max_depth=max_depth, aux=True)
-        got["spilled"] = dev.debug_last_spilled()
+        got["regrown"] = dev.debug_last_regrown()
     finally:
         dev.close()
     want = oscene.render(max_depth=max_depth)
@@ -149,10 +149,10 @@ def test_ragged_frame_size(scenes_dir, model_dir):
 
 
 def test_queue_overflow_is_harmless(scenes_dir, model_dir):
-    # a queue far too small for the frame: children are traced by their parent lane instead
+    # ray lists far too short for the frame: rt_render notices, enlarges them and renders the frame again
     s = load(scenes_dir, model_dir, "cornell_box", 320, 180)
     got, want = render_both(s, queue_capacity=1000)
-    assert got["spilled"] > 0
+    assert got["regrown"] > 0
     assert_parity(got, want)
 
 
