@@ -9,6 +9,9 @@ RCCL and every rank assembles the frame - the total work is fixed, so scaling is
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
         bench.py --gpus N --steps K --warmup W
 
+A rank keeps --frames-in-flight (default 3) frames queued, each on its own scene handle and stream; `value` is that
+rate, the "sequential" object of the JSON line the rate with one frame at a time.
+
 Rank 0 prints one JSON line.  The scene's bunny.obj is not part of the reference repository; a
 deterministic stand-in of 81 920 triangles is generated (rust_raytracer_amd/meshes.py) unless a real
 bunny.obj is found in --model-dir.
@@ -89,6 +92,8 @@ def main():
     ap.add_argument("--workload", default="reflective_bunnies_1080p", choices=sorted(WORKLOADS))
     ap.add_argument("--model-dir", default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--frames-in-flight", type=int, default=3,
+                    help="independent frames a rank keeps queued (own scene handle, stream and buffers each); 1 = one after the other")
     args = ap.parse_args()
 
     import numpy as np
@@ -127,22 +132,37 @@ def main():
 
     host = native.HostScene.load(scene_path, model_dir)
     host.resize_screen(width, height)
-    dev = native.DeviceScene(host.desc(), local_rank)
     m, w, h = host.camera()
-    dev.set_camera(m, w, h)
     n_tris = host.desc().n_mesh_triangles
 
-    stream = torch.cuda.Stream()
-    torch.cuda.set_stream(stream)
-    handle = stream.cuda_stream
+    # A frame is a chain of short dependent launches (five per recursion depth), so one frame alone leaves the
+    # chip partly idle at every link.  A rank therefore keeps `depth` frames queued, as a renderer producing an
+    # animation or a batch of views does: slot k has its own scene handle (own ray lists), stream and output buffers,
+    # frame i goes to slot i % depth.  Every frame is still rendered completely, gathered and assembled.
+    depth = max(1, args.frames_in_flight)
 
-    def render_shard(out):
-        dev.render_device(out.data_ptr(), max_depth=max_depth, shard_index=rank, shard_count=world, stream=handle)
+    class Slot:
+        def __init__(self):
+            self.dev = native.DeviceScene(host.desc(), local_rank)
+            self.dev.set_camera(m, w, h)
+            self.stream = torch.cuda.Stream()
+            handle = self.stream.cuda_stream
+            dev = self.dev
 
-    def assemble(gathered, frame):
-        dev.assemble_shards(gathered.data_ptr(), frame.data_ptr(), world, stream=handle)
+            def render_shard(out):
+                dev.render_device(out.data_ptr(), max_depth=max_depth, shard_index=rank, shard_count=world, stream=handle)
 
-    sf = sharding.ShardedFrame(w, h, 3, rank, world, "cuda", render_shard, assemble)
+            def assemble(gathered, frame):
+                dev.assemble_shards(gathered.data_ptr(), frame.data_ptr(), world, stream=handle)
+
+            self.sf = sharding.ShardedFrame(w, h, 3, rank, world, "cuda", render_shard, assemble)
+
+        def step(self):
+            with torch.cuda.stream(self.stream):       # the all-gather orders itself against torch's current stream
+                self.sf.step()
+
+    slots = [Slot() for _ in range(depth)]
+    dev, sf = slots[0].dev, slots[0].sf
 
     def barrier():
         torch.cuda.synchronize()
@@ -150,18 +170,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        sf.step()
+    for k in range(max(args.warmup, depth if args.warmup else 0)):
+        slots[k % depth].step()
         torch.cuda.synchronize()      # a frame whose ray lists overflowed is noticed by the next one: let it finish
     barrier()
-    trace_ms = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sf.step()
-        # HIP events recorded by the library on the launch stream; reading them back does not
-        # synchronise (the elapsed times are collected after the timed region)
+    for k in range(args.steps):
+        slots[k % depth].step()
     barrier()
     elapsed = time.perf_counter() - t0
+    for s in slots:
+        s.dev.last_ray_counts()       # raises if a frame of the timed region overflowed its ray lists
+
+    # The same steps one after the other on one slot, for the latency of a single frame.
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        slots[0].step()
+    barrier()
+    elapsed_sequential = time.perf_counter() - t0
     trace_ms = dev.last_trace_ms()
     frame_ms = dev.last_render_ms()
     counts = dev.last_ray_counts().astype(np.int64)
@@ -172,21 +199,23 @@ def main():
     kernel_ms = {k: [0.0, 0] for k in dev.LEVEL_KERNELS}
     dev.set_kernel_timing(True)
     for _ in range(args.steps):
-        sf.step()
+        slots[0].step()
         for k, (ms, n) in dev.last_kernel_ms().items():        # waits for this frame's last event
             kernel_ms[k][0] += ms
             kernel_ms[k][1] += n
     dev.set_kernel_timing(False)
     barrier()
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    t = torch.tensor([elapsed, elapsed_sequential], dtype=torch.float64, device="cuda")
     rays = torch.tensor(counts[:5], dtype=torch.int64, device="cuda")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
-    elapsed = float(t.item())
+    elapsed, elapsed_sequential = (float(x) for x in t.cpu())
     rays = rays.cpu().numpy()
     frame_check = sf.frame.cpu().numpy().reshape(h, w, 3)
+    for other in slots[1:]:
+        assert torch.equal(other.sf.frame, sf.frame), "slots rendered different frames"
 
     if rank == 0:
         rays_per_frame = int(rays[0])
@@ -203,7 +232,11 @@ def main():
                                if n_tris else "none",
                        "rays_per_frame": rays_per_frame, "primary": int(rays[1]), "shadow": int(rays[2]),
                        "reflected": int(rays[3]), "transmitted": int(rays[4]),
+                       "frames_in_flight": depth,
                        "parallelism": "tile-sharded x%d, scene replicated, RCCL all-gather" % world if world > 1 else "single GPU"},
+            # one frame at a time (the next is issued behind the previous one on the same stream)
+            "sequential": {"value": rays_per_frame * args.steps / elapsed_sequential / 1e6, "unit": "Mrays/s",
+                           "ms_per_step": elapsed_sequential / args.steps * 1e3},
         }
         baseline = None
         ref_counters = None
@@ -243,7 +276,8 @@ def main():
         out["roofline"] = roofline
         out["frame_checksum"] = int(np.asarray(frame_check, dtype=np.uint64).sum())
         print(json.dumps(out))
-    dev.close()
+    for s in slots:
+        s.dev.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
