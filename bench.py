@@ -94,7 +94,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--frames-in-flight", type=int, default=3,
                     help="independent frames a rank keeps queued (own scene handle, stream and buffers each); 1 = one after the other")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="all ranks share cuda:0 and gather over gloo: checks the N>1 code path on a one-GPU box, not a measurement")
+    ap.add_argument("--watchdog", type=int, default=900, help="seconds after which a stuck run prints its stacks and exits (0 = off)")
     args = ap.parse_args()
+    if args.watchdog:
+        import faulthandler
+        faulthandler.dump_traceback_later(args.watchdog, exit=True)
 
     import numpy as np
     import torch
@@ -110,8 +116,12 @@ def main():
         sys.exit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 and args.rehearse_on_one_gpu:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    elif world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     scene_file, width, height, max_depth = WORKLOADS[args.workload]
@@ -141,6 +151,15 @@ def main():
     # frame i goes to slot i % depth.  Every frame is still rendered completely, gathered and assembled.
     depth = max(1, args.frames_in_flight)
 
+    def host_staged_gather(gathered, shard):
+        # Rehearsal only.  gloo's own device path puts high-priority streams behind events, and with two processes
+        # on one GPU such a wait can hang; go through host memory instead (this stops the pipeline at every frame).
+        torch.cuda.current_stream().synchronize()
+        mine = shard.cpu()
+        everyone = torch.empty(mine.numel() * world, dtype=torch.uint8)
+        dist.all_gather_into_tensor(everyone, mine)
+        gathered.copy_(everyone)
+
     class Slot:
         def __init__(self):
             self.dev = native.DeviceScene(host.desc(), local_rank)
@@ -155,7 +174,8 @@ def main():
             def assemble(gathered, frame):
                 dev.assemble_shards(gathered.data_ptr(), frame.data_ptr(), world, stream=handle)
 
-            self.sf = sharding.ShardedFrame(w, h, 3, rank, world, "cuda", render_shard, assemble)
+            self.sf = sharding.ShardedFrame(w, h, 3, rank, world, "cuda", render_shard, assemble,
+                                            host_staged_gather if args.rehearse_on_one_gpu else None)
 
         def step(self):
             with torch.cuda.stream(self.stream):       # the all-gather orders itself against torch's current stream
@@ -233,7 +253,8 @@ def main():
                        "rays_per_frame": rays_per_frame, "primary": int(rays[1]), "shadow": int(rays[2]),
                        "reflected": int(rays[3]), "transmitted": int(rays[4]),
                        "frames_in_flight": depth,
-                       "parallelism": "tile-sharded x%d, scene replicated, RCCL all-gather" % world if world > 1 else "single GPU"},
+                       "parallelism": ("tile-sharded x%d, scene replicated, %s" % (world, "REHEARSAL: ranks share one GPU, gloo"
+                                       if args.rehearse_on_one_gpu else "RCCL all-gather")) if world > 1 else "single GPU"},
             # one frame at a time (the next is issued behind the previous one on the same stream)
             "sequential": {"value": rays_per_frame * args.steps / elapsed_sequential / 1e6, "unit": "Mrays/s",
                            "ms_per_step": elapsed_sequential / args.steps * 1e3},

@@ -63,10 +63,11 @@ class ShardedFrame:
 
     `render_shard(out_tensor)` fills this rank's shard buffer, `assemble_fn(gathered, frame)` turns
     the gathered buffers into the frame; both are injected so that the same driver runs over the
-    HIP library on GPUs (bench.py) and over numpy on CPU ranks (tests, gloo).
+    HIP library on GPUs (bench.py) and over numpy on CPU ranks (tests, gloo).  `gather_fn(gathered, shard)`
+    defaults to torch.distributed.all_gather_into_tensor.
     """
 
-    def __init__(self, width, height, channels, rank, world_size, device, render_shard, assemble_fn):
+    def __init__(self, width, height, channels, rank, world_size, device, render_shard, assemble_fn, gather_fn=None):
         import torch
         self.torch = torch
         self.rank, self.world = rank, world_size
@@ -76,13 +77,16 @@ class ShardedFrame:
         self.frame = torch.zeros(height * width * channels, dtype=torch.uint8, device=device)
         self.gathered = torch.zeros(nbytes * world_size, dtype=torch.uint8, device=device) if world_size > 1 else None
         self.render_shard, self.assemble_fn = render_shard, assemble_fn
+        if gather_fn is None:
+            import torch.distributed as dist
+            gather_fn = dist.all_gather_into_tensor
+        self.gather_fn = gather_fn
 
     def step(self):
         if self.world == 1:
             self.render_shard(self.frame)
             return self.frame
-        import torch.distributed as dist
         self.render_shard(self.shard)
-        dist.all_gather_into_tensor(self.gathered, self.shard)      # the frame's one exchange step
+        self.gather_fn(self.gathered, self.shard)                   # the frame's one exchange step
         self.assemble_fn(self.gathered, self.frame)
         return self.frame
