@@ -9,8 +9,10 @@ RCCL and every rank assembles the frame - the total work is fixed, so scaling is
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
         bench.py --gpus N --steps K --warmup W
 
-A rank keeps --frames-in-flight (default 3) frames queued, each on its own scene handle and stream; `value` is that
-rate, the "sequential" object of the JSON line the rate with one frame at a time.
+The timed frames are rendered the way a renderer with a queue of frames would: --views-per-pass frames travel through
+the recursion depths together (rt_scene_set_views; by default up to four whole frames' worth of pixels per rank), and a
+rank keeps --frames-in-flight (default 3) such passes queued, each on its own scene handle and stream.  `value` is
+that rate; the "sequential" object of the JSON line is the rate with one frame at a time.
 
 Rank 0 prints one JSON line.  The scene's bunny.obj is not part of the reference repository; a
 deterministic stand-in of 81 920 triangles is generated (rust_raytracer_amd/meshes.py) unless a real
@@ -87,13 +89,15 @@ def cpu_baseline(scene_path, model_dir, width, height, max_depth, budget_s=12.0)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=48)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="reflective_bunnies_1080p", choices=sorted(WORKLOADS))
     ap.add_argument("--model-dir", default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--frames-in-flight", type=int, default=3,
                     help="independent frames a rank keeps queued (own scene handle, stream and buffers each); 1 = one after the other")
+    ap.add_argument("--views-per-pass", type=int, default=0,
+                    help="frames that travel through the recursion depths together (rt_scene_set_views); 0 = chosen from --steps and --gpus")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="all ranks share cuda:0 and gather over gloo: checks the N>1 code path on a one-GPU box, not a measurement")
     ap.add_argument("--watchdog", type=int, default=900, help="seconds after which a stuck run prints its stacks and exits (0 = off)")
@@ -105,7 +109,7 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    from rust_raytracer_amd import meshes, native, sharding
+    from rust_raytracer_amd import abi, meshes, native, sharding
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -150,6 +154,15 @@ def main():
     # animation or a batch of views does: slot k has its own scene handle (own ray lists), stream and output buffers,
     # frame i goes to slot i % depth.  Every frame is still rendered completely, gathered and assembled.
     depth = max(1, args.frames_in_flight)
+    # Frames of one pass share every launch (rt_scene_set_views): the fixed cost of a recursion depth - launches, prefix
+    # tables, the longest BVH walk - is paid once for all of them, which matters most for the small shards of many ranks.
+    views = args.views_per_pass
+    if views <= 0:
+        # as many as make four 1080p frames' worth of pixels per rank, leaving at least two passes to overlap
+        cap = max(1, min(abi.RT_MAX_VIEWS, 4 * 1920 * 1080 * world // (w * h)))
+        views = max([v for v in range(1, cap + 1) if args.steps // v >= 2] or [1])
+    views = max(1, min(views, abi.RT_MAX_VIEWS, max(args.steps, 1)))
+    passes, leftover = divmod(args.steps, views)       # the frames that do not fill a pass get a smaller pass of their own
 
     def host_staged_gather(gathered, shard):
         # Rehearsal only.  gloo's own device path puts high-priority streams behind events, and with two processes
@@ -161,9 +174,10 @@ def main():
         gathered.copy_(everyone)
 
     class Slot:
-        def __init__(self):
+        def __init__(self, views):
+            self.views = views
             self.dev = native.DeviceScene(host.desc(), local_rank)
-            self.dev.set_camera(m, w, h)
+            self.dev.set_views(np.tile(np.asarray(m, dtype=np.float32).reshape(1, 16), (views, 1)), w, h)
             self.stream = torch.cuda.Stream()
             handle = self.stream.cuda_stream
             dev = self.dev
@@ -175,13 +189,15 @@ def main():
                 dev.assemble_shards(gathered.data_ptr(), frame.data_ptr(), world, stream=handle)
 
             self.sf = sharding.ShardedFrame(w, h, 3, rank, world, "cuda", render_shard, assemble,
-                                            host_staged_gather if args.rehearse_on_one_gpu else None)
+                                            host_staged_gather if args.rehearse_on_one_gpu else None, views=views)
 
         def step(self):
             with torch.cuda.stream(self.stream):       # the all-gather orders itself against torch's current stream
                 self.sf.step()
 
-    slots = [Slot() for _ in range(depth)]
+    slots = [Slot(views) for _ in range(depth)]
+    last_slot = Slot(leftover) if leftover else None
+    every_slot = slots + ([last_slot] if last_slot else [])
     dev, sf = slots[0].dev, slots[0].sf
 
     def barrier():
@@ -190,28 +206,44 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for k in range(max(args.warmup, depth if args.warmup else 0)):
+    for k in range(max(-(-args.warmup // views), depth if args.warmup else 0)):
         slots[k % depth].step()
         torch.cuda.synchronize()      # a frame whose ray lists overflowed is noticed by the next one: let it finish
+    if last_slot and args.warmup:
+        last_slot.step()
     barrier()
     t0 = time.perf_counter()
-    for k in range(args.steps):
+    for k in range(passes):           # args.steps frames: `views` per pass ...
         slots[k % depth].step()
+    if last_slot:
+        last_slot.step()              # ... and the rest
     barrier()
     elapsed = time.perf_counter() - t0
-    for s in slots:
+    for s in every_slot:
         s.dev.last_ray_counts()       # raises if a frame of the timed region overflowed its ray lists
+    counts = dev.last_ray_counts().astype(np.int64) // views            # per frame (the views are the same frame)
+    frame_check = sf.frame[:h * w * 3].cpu().numpy().reshape(h, w, 3)
+    for other in every_slot:
+        assert torch.equal(other.sf.frame.view(other.views, -1), sf.frame[:h * w * 3].expand(other.views, -1)), \
+            "frames of the timed region differ"
 
-    # The same steps one after the other on one slot, for the latency of a single frame.
+    # The same number of frames one at a time on one handle and one stream, for the latency of a single frame; the
+    # per-kernel pass further down runs this way too, so that a launch's duration is its own.
+    dev.set_camera(m, w, h)
+    one = Slot.__new__(Slot)
+    one.dev, one.stream, one.views = dev, slots[0].stream, 1
+    one.sf = sharding.ShardedFrame(w, h, 3, rank, world, "cuda", slots[0].sf.render_shard, slots[0].sf.assemble_fn,
+                                   host_staged_gather if args.rehearse_on_one_gpu else None)
+    one.step(); one.step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        slots[0].step()
+        one.step()
     barrier()
     elapsed_sequential = time.perf_counter() - t0
     trace_ms = dev.last_trace_ms()
     frame_ms = dev.last_render_ms()
-    counts = dev.last_ray_counts().astype(np.int64)
+    assert np.array_equal(one.sf.frame.cpu().numpy().reshape(h, w, 3), frame_check), "a frame rendered alone differs"
 
     # Per-kernel durations, live: the same steps once more with every launch of the four per-depth
     # kernels bracketed by HIP events on the launch stream (outside the timed region above, so that
@@ -219,7 +251,7 @@ def main():
     kernel_ms = {k: [0.0, 0] for k in dev.LEVEL_KERNELS}
     dev.set_kernel_timing(True)
     for _ in range(args.steps):
-        slots[0].step()
+        one.step()
         for k, (ms, n) in dev.last_kernel_ms().items():        # waits for this frame's last event
             kernel_ms[k][0] += ms
             kernel_ms[k][1] += n
@@ -233,9 +265,6 @@ def main():
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
     elapsed, elapsed_sequential = (float(x) for x in t.cpu())
     rays = rays.cpu().numpy()
-    frame_check = sf.frame.cpu().numpy().reshape(h, w, 3)
-    for other in slots[1:]:
-        assert torch.equal(other.sf.frame, sf.frame), "slots rendered different frames"
 
     if rank == 0:
         rays_per_frame = int(rays[0])
@@ -252,7 +281,7 @@ def main():
                                if n_tris else "none",
                        "rays_per_frame": rays_per_frame, "primary": int(rays[1]), "shadow": int(rays[2]),
                        "reflected": int(rays[3]), "transmitted": int(rays[4]),
-                       "frames_in_flight": depth,
+                       "frames_in_flight": depth * views, "passes_in_flight": depth, "views_per_pass": views,
                        "parallelism": ("tile-sharded x%d, scene replicated, %s" % (world, "REHEARSAL: ranks share one GPU, gloo"
                                        if args.rehearse_on_one_gpu else "RCCL all-gather")) if world > 1 else "single GPU"},
             # one frame at a time (the next is issued behind the previous one on the same stream)
@@ -297,7 +326,7 @@ def main():
         out["roofline"] = roofline
         out["frame_checksum"] = int(np.asarray(frame_check, dtype=np.uint64).sum())
         print(json.dumps(out))
-    for s in slots:
+    for s in every_slot:
         s.dev.close()
     if world > 1:
         dist.barrier()

@@ -186,7 +186,7 @@ enum {
     RT_N_COUNTERS
 };
 
-typedef struct RtAux {
+typedef struct RtAux {              /* with several views (rt_scene_set_views): n_views * W*H entries per array */
     uint32_t* prim_id;        /* W*H, row 0 = top, or NULL */
     uint32_t* instance_id;    /* W*H or NULL */
     uint8_t* flags;           /* W*H or NULL */
@@ -224,6 +224,18 @@ int rt_scene_create(const RtSceneDesc* desc, int device_id, RtScene** out_scene)
  * Scene::screen_to_world() (scene.rs:50-52), column-major; width/height are camera.screen_dimensions. */
 int rt_scene_set_camera(RtScene* scene, const float screen_to_world[16], uint32_t width, uint32_t height);
 
+/* Several views of the scene rendered by one call, all of the same size: `screen_to_world` holds n_views matrices
+ * (16 floats each) back to back, 1 <= n_views <= RT_MAX_VIEWS.  rt_render / rt_render_device then produce n_views
+ * frames (or shards) back to back in the output, view v at byte offset v * (size of one frame or shard); the RtAux
+ * arrays hold n_views * W*H entries; rt_assemble_shards expects every rank's buffer to hold its n_views shards and
+ * writes n_views frames; the ray counts and times are those of all views together.  The views travel through every
+ * recursion depth together, so the fixed cost of a depth (launches, the longest BVH walk) is paid once for all of
+ * them: small frames and shards render markedly faster per view this way.  rt_scene_set_camera is the case n_views = 1.
+ * The reference has no counterpart: its renderers draw one camera per call (gpu_renderer.rs:280, main.rs:46-66);
+ * a caller with a queue of frames (an animation, the batch of orbit views) would loop over it. */
+#define RT_MAX_VIEWS 32
+int rt_scene_set_views(RtScene* scene, const float* screen_to_world, uint32_t n_views, uint32_t width, uint32_t height);
+
 /* Replaces paint_scene (native_app/src/main.rs:46-66) and GpuRenderer::render (gpu_renderer.rs:280-354):
  * renders the whole frame (shard fields of `params` are ignored) and copies it to `out_pixels`
  * (host memory, W*H*3 or W*H*4 bytes, row 0 = top as canvas.rs:35-46).  `aux` may be NULL; its
@@ -237,7 +249,7 @@ int rt_render(RtScene* scene, const RtRenderParams* params, uint8_t* out_pixels,
  * tile; pixels outside the frame are zero.  Use rt_shard_bytes for the buffer size. */
 int rt_render_device(RtScene* scene, const RtRenderParams* params, void* d_out);
 
-/* Bytes one shard writes in rt_render_device (equal for every shard_index: the tile count is
+/* Bytes one shard writes in rt_render_device per view (equal for every shard_index: the tile count is
  * rounded up to a multiple of shard_count so that gathers are uniform). */
 int rt_shard_bytes(const RtScene* scene, const RtRenderParams* params, uint64_t* out_bytes);
 

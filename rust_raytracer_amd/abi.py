@@ -28,6 +28,7 @@ COUNTER_NAMES = ["rays", "primary", "shadow", "reflected", "transmitted", "aabb_
                  "triangle_tests", "sphere_tests", "plane_tests", "instance_transforms", "mesh_hits", "light_shades"]
 RT_FORMAT_RGB8, RT_FORMAT_RGBA8 = 0, 1
 RT_TILE_DIM = 32
+RT_MAX_VIEWS = 32
 
 f32, u32, i32 = C.c_float, C.c_uint32, C.c_int32
 

@@ -15,13 +15,14 @@
 #include "rt_device.h"
 
 extern "C" {
-hipError_t rt_launch_generate(const DFrame* F, uint32_t blocks, hipStream_t stream);
+hipError_t rt_launch_generate(const DFrame* F, const DViews* V, uint32_t blocks, hipStream_t stream);
 hipError_t rt_launch_level(const DScene* S, const DFrame* F, uint32_t level, uint32_t blocks, uint32_t traverse_blocks,
                            hipStream_t stream, hipEvent_t* marks);
 hipError_t rt_launch_resolve(const DFrame* F, uint8_t* out, uint32_t bytes_per_pixel, uint32_t tiled, hipStream_t stream);
 hipError_t rt_launch_resolve_aux(const DFrame* F, uint32_t* prim, uint32_t* inst, uint8_t* flags, hipStream_t stream);
 hipError_t rt_launch_assemble(const uint8_t* gathered, uint8_t* frame, uint32_t width, uint32_t height, uint32_t tiles_x,
-                              uint32_t shard_count, uint32_t tiles_per_shard, uint32_t bytes_per_pixel, hipStream_t stream);
+                              uint32_t shard_count, uint32_t tiles_per_shard, uint32_t bytes_per_pixel, uint32_t n_views,
+                              hipStream_t stream);
 int rt_query_traverse_blocks_per_cu(uint32_t n_seg, uint32_t stack_entries);
 }
 
@@ -60,7 +61,8 @@ struct RtScene {
     std::vector<void*> scene_allocs;
     DScene d{};
     bool camera_set = false;
-    float screen_to_world[16] = {};
+    DViews views{};                     // screen_to_world of every view
+    uint32_t n_views = 1;
     uint32_t width = 0, height = 0;
     // per-frame buffers, reallocated when the key below changes
     struct FrameKey { uint32_t w = 0, h = 0, shard_count = 0, max_depth = 0, aux = 0, blocks = 0, capacity = 0; } key;
@@ -460,19 +462,28 @@ extern "C" void rt_scene_destroy(RtScene* s) {
     delete s;
 }
 
-extern "C" int rt_scene_set_camera(RtScene* s, const float screen_to_world[16], uint32_t width, uint32_t height) {
-    if (!s || !screen_to_world) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_set_camera: null argument");
-    if (width == 0 || height == 0) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_set_camera: empty screen %ux%u", width, height);
-    memcpy(s->screen_to_world, screen_to_world, 64);
+extern "C" int rt_scene_set_views(RtScene* s, const float* screen_to_world, uint32_t n_views, uint32_t width, uint32_t height) {
+    if (!s || !screen_to_world) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_set_views: null argument");
+    if (width == 0 || height == 0) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_set_views: empty screen %ux%u", width, height);
+    if (n_views == 0 || n_views > RT_MAX_VIEWS)
+        return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_set_views: %u views; between 1 and %d are supported", n_views, RT_MAX_VIEWS);
+    memcpy(s->views.m, screen_to_world, (size_t)n_views * 64);
+    s->n_views = n_views;
     s->width = width;
     s->height = height;
     s->camera_set = true;
     return RT_OK;
 }
 
+extern "C" int rt_scene_set_camera(RtScene* s, const float screen_to_world[16], uint32_t width, uint32_t height) {
+    if (!s || !screen_to_world) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_set_camera: null argument");
+    if (width == 0 || height == 0) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_set_camera: empty screen %ux%u", width, height);
+    return rt_scene_set_views(s, screen_to_world, 1, width, height);
+}
+
 static uint32_t bytes_per_pixel(uint32_t format) { return format == RT_FORMAT_RGBA8 ? 4u : 3u; }
 
-struct Geometry { uint32_t tiles_x, tiles_y, shard_count, shard_index, tiles_per_shard, n_pixels; };
+struct Geometry { uint32_t tiles_x, tiles_y, shard_count, shard_index, tiles_per_shard, view_pixels, n_pixels; };
 
 static int frame_geometry(const RtScene* s, const RtRenderParams* p, bool sharded, Geometry* g) {
     if (!s->camera_set) return fail(RT_ERR_INVALID_ARGUMENT, "the camera has not been set (rt_scene_set_camera)");
@@ -484,8 +495,11 @@ static int frame_geometry(const RtScene* s, const RtRenderParams* p, bool sharde
     if (g->shard_index >= g->shard_count) return fail(RT_ERR_INVALID_ARGUMENT, "shard_index %u >= shard_count %u", g->shard_index, g->shard_count);
     uint64_t tiles = (uint64_t)g->tiles_x * g->tiles_y;
     g->tiles_per_shard = (uint32_t)((tiles + g->shard_count - 1) / g->shard_count);
-    uint64_t n_pixels = (uint64_t)g->tiles_per_shard * RT_TILE_DIM * RT_TILE_DIM;
-    if (n_pixels > RT_MAX_PIXELS_PER_SHARD) return fail(RT_ERR_INVALID_ARGUMENT, "%llu pixels per shard exceed the limit of %u", (unsigned long long)n_pixels, RT_MAX_PIXELS_PER_SHARD);
+    uint64_t view_pixels = (uint64_t)g->tiles_per_shard * RT_TILE_DIM * RT_TILE_DIM, n_pixels = view_pixels * s->n_views;
+    if (n_pixels > RT_MAX_PIXELS_PER_SHARD)
+        return fail(RT_ERR_INVALID_ARGUMENT, "%llu pixels per shard (%u views together) exceed the limit of %u",
+                    (unsigned long long)n_pixels, s->n_views, RT_MAX_PIXELS_PER_SHARD);
+    g->view_pixels = (uint32_t)view_pixels;
     g->n_pixels = (uint32_t)n_pixels;
     return RT_OK;
 }
@@ -568,11 +582,10 @@ static int ensure_frame(RtScene* s, const Geometry& g, uint32_t max_depth, bool 
         s->key = k;
     }
     DFrame& f = s->f;
-    memcpy(f.screen_to_world, s->screen_to_world, 64);
     f.width = s->width; f.height = s->height;
     f.tiles_x = g.tiles_x; f.tiles_y = g.tiles_y;
     f.shard_index = g.shard_index; f.shard_count = g.shard_count;
-    f.n_local_tiles = g.tiles_per_shard; f.n_pixels = g.n_pixels;
+    f.n_local_tiles = g.tiles_per_shard; f.view_pixels = g.view_pixels; f.n_views = s->n_views; f.n_pixels = g.n_pixels;
     f.max_depth = max_depth;
     return RT_OK;
 }
@@ -601,7 +614,7 @@ static int enqueue_frame(RtScene* s, const RtRenderParams* p, bool sharded, bool
     HIP_TRY(hipMemsetAsync(f.ray_counts[0], 0, s->counter_words * sizeof(unsigned int), stream));  // every counter + statistics
     if (aux) HIP_TRY(hipMemsetAsync(f.aux_flags, 0, (size_t)g.n_pixels * sizeof(unsigned int), stream));
     HIP_TRY(hipEventRecord(s->ev_trace_start, stream));
-    HIP_TRY(rt_launch_generate(&f, s->list_blocks, stream));
+    HIP_TRY(rt_launch_generate(&f, &s->views, s->list_blocks, stream));
     // a depth map only looks at the primary hits
     const uint32_t last = p->mode == RT_MODE_DEPTH_MAP ? 0 : (s->d.n_lights > 0 ? max_depth : max_depth - 1);
     s->marked_levels = 0;
@@ -628,7 +641,7 @@ extern "C" int rt_shard_bytes(const RtScene* s, const RtRenderParams* p, uint64_
     Geometry g;
     int rc = frame_geometry(s, p, true, &g);
     if (rc) return rc;
-    if (g.shard_count > 1) *out_bytes = (uint64_t)g.n_pixels * bytes_per_pixel(p->output_format);
+    if (g.shard_count > 1) *out_bytes = (uint64_t)g.view_pixels * bytes_per_pixel(p->output_format);
     else *out_bytes = (uint64_t)s->width * s->height * bytes_per_pixel(p->output_format);
     return RT_OK;
 }
@@ -642,7 +655,7 @@ extern "C" int rt_render(RtScene* s, const RtRenderParams* p, uint8_t* out_pixel
     if (!s || !p || !out_pixels) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: null argument");
     HIP_TRY(hipSetDevice(s->device));
     if (!s->camera_set) return fail(RT_ERR_INVALID_ARGUMENT, "the camera has not been set (rt_scene_set_camera)");
-    size_t n = (size_t)s->width * s->height;
+    size_t n = (size_t)s->width * s->height * s->n_views;
     size_t bytes = n * bytes_per_pixel(p->output_format);
     if (s->d_pixels_bytes < bytes) {
         if (s->d_pixels) (void)hipFree(s->d_pixels);
@@ -697,11 +710,11 @@ extern "C" int rt_assemble_shards(RtScene* s, const RtRenderParams* p, const voi
     hipStream_t stream = p->stream ? (hipStream_t)p->stream : s->own_stream;
     uint32_t bpp = bytes_per_pixel(p->output_format);
     if (g.shard_count <= 1) {
-        HIP_TRY(hipMemcpyAsync(d_frame, d_gathered, (size_t)s->width * s->height * bpp, hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(d_frame, d_gathered, (size_t)s->width * s->height * bpp * s->n_views, hipMemcpyDeviceToDevice, stream));
         return RT_OK;
     }
     HIP_TRY(rt_launch_assemble(static_cast<const uint8_t*>(d_gathered), static_cast<uint8_t*>(d_frame), s->width, s->height,
-                               g.tiles_x, g.shard_count, g.tiles_per_shard, bpp, stream));
+                               g.tiles_x, g.shard_count, g.tiles_per_shard, bpp, s->n_views, stream));
     return RT_OK;
 }
 

@@ -110,6 +110,9 @@ struct DScene {
     const float4* tri_cold;
 };
 
+// The cameras of the views of a frame (rt_generate's own argument): column-major screen_to_world matrices.
+struct DViews { float m[RT_MAX_VIEWS][16]; };
+
 // Per-frame device state.
 //
 // Work lists (rays, BVH work items, hit records) are cut into one segment per producer block plus
@@ -119,12 +122,13 @@ struct DScene {
 // all segments in interleaved 64-element chunks, so that work is spread evenly again whatever
 // block produced it.
 struct DFrame {
-    float screen_to_world[16];       // column-major
     uint32_t width, height;
     uint32_t tiles_x, tiles_y;
     uint32_t shard_index, shard_count;
     uint32_t n_local_tiles;          // tiles this shard owns (rounded up so every shard has the same number)
-    uint32_t n_pixels;               // n_local_tiles * RT_TILE_DIM^2
+    uint32_t view_pixels;            // n_local_tiles * RT_TILE_DIM^2: local pixels of one view
+    uint32_t n_views;                // views rendered together; local pixel p belongs to view p / view_pixels
+    uint32_t n_pixels;               // n_views * view_pixels
     uint32_t max_depth;
     uint32_t mode;                   // RT_MODE_*
     uint32_t n_seg;                  // producer blocks + 1 (the last segment is the shared overflow segment)

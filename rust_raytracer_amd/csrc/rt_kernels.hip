@@ -335,8 +335,10 @@ __device__ __forceinline__ RayRec load_rec(const float4* q, uint32_t i) {
     return rr;
 }
 
-// local pixel index -> canvas (col, row); false for padding pixels outside the frame
-__device__ __forceinline__ bool pixel_coords(const DFrame& F, uint32_t p, uint32_t& col, uint32_t& row) {
+// local pixel index -> view and canvas (col, row); false for padding pixels outside the frame
+__device__ __forceinline__ bool pixel_coords(const DFrame& F, uint32_t p, uint32_t& view, uint32_t& col, uint32_t& row) {
+    view = p / F.view_pixels;
+    p -= view * F.view_pixels;
     uint32_t k = p / (RT_TILE_DIM * RT_TILE_DIM), q = p % (RT_TILE_DIM * RT_TILE_DIM);
     uint32_t tile = F.shard_index + k * F.shard_count;
     if (tile >= F.tiles_x * F.tiles_y) return false;
@@ -348,8 +350,7 @@ __device__ __forceinline__ bool pixel_coords(const DFrame& F, uint32_t p, uint32
 }
 
 // raytracer.rs:30-51 for canvas pixel (col, row); screen y = H-1-row (canvas.rs:35-46)
-__device__ __forceinline__ Ray primary_ray(const DFrame& F, uint32_t col, uint32_t row) {
-    const float* m = F.screen_to_world;
+__device__ __forceinline__ Ray primary_ray(const DFrame& F, const float* m, uint32_t col, uint32_t row) {
     float x = (float)col, y = (float)(F.height - 1 - row);
     float p[4] = {x, y, 0.0f, 1.0f};
     float pf[4] = {x + 0.0f, y + 0.0f, 0.0f + 1.0f, 1.0f + 0.0f};
@@ -622,7 +623,7 @@ __host__ __device__ inline uint32_t analytic_stage_words(const DScene& S) {
 // ======================================================================================================
 // Kernel 0: primary rays (raytracer.rs:30-51) for this shard's pixels -> ray list of depth 0.
 // ======================================================================================================
-__global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_generate(const DFrame F) {
+__global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_generate(const DFrame F, const DViews V) {
     __shared__ uint32_t out_n;
     if (threadIdx.x == 0) out_n = 0;
     __syncthreads();
@@ -631,11 +632,13 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_generate(const DFrame F) 
     const uint32_t n_waves = gridDim.x * (blockDim.x / RT_WAVE);
     for (uint32_t c = gwave; (unsigned long long)c * RT_WAVE < F.n_pixels; c += n_waves) {
         const uint32_t p = c * RT_WAVE + lane;
-        uint32_t col = 0, row = 0;
-        const bool inside = p < F.n_pixels && pixel_coords(F, p, col, row);
+        uint32_t view = 0, col = 0, row = 0;
+        const bool inside = p < F.n_pixels && pixel_coords(F, p, view, col, row);
         RayRec rr;
         rr.ray.o = rr.ray.d = mk(0, 0, 0);
-        if (inside) rr.ray = primary_ray(F, col, row);
+        // a wave's 64 pixels lie in one view (view_pixels is a multiple of 64): the matrix index is wave-uniform
+        const uint32_t wave_view = __builtin_amdgcn_readfirstlane(c * RT_WAVE / F.view_pixels);
+        if (inside) rr.ray = primary_ray(F, V.m[wave_view < F.n_views ? wave_view : 0], col, row);
         rr.throughput = 1.0f;
         rr.meta = p;
         uint32_t slot = append_slot(inside, &out_n, F.seg_rays, F.n_seg, F.ray_counts[0], F.ovf_rays, F.overflow, lane);
@@ -1623,8 +1626,8 @@ __global__ void __launch_bounds__(RT_SHADE_THREADS) rt_shade(const DScene S, con
 __global__ void rt_resolve(const DFrame F, uint8_t* out, uint32_t bytes_per_pixel, uint32_t tiled) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= F.n_pixels) return;
-    uint32_t col = 0, row = 0;
-    bool inside = pixel_coords(F, p, col, row);
+    uint32_t view = 0, col = 0, row = 0;
+    bool inside = pixel_coords(F, p, view, col, row);
     uint8_t rgb[3] = {0, 0, 0};
     if (inside) {
         unsigned int poison = F.poison[p];
@@ -1643,15 +1646,15 @@ __global__ void rt_resolve(const DFrame F, uint8_t* out, uint32_t bytes_per_pixe
             rgb[c] = (uint8_t)(int)(clamped * 255.0f);                        // `as u8` truncates
         }
     }
-    size_t at;
+    size_t at;                                                      // view v starts at v * (bytes of one shard or frame)
     if (tiled) {
-        uint32_t k = p / (RT_TILE_DIM * RT_TILE_DIM), q = p % (RT_TILE_DIM * RT_TILE_DIM);
+        uint32_t k = p / (RT_TILE_DIM * RT_TILE_DIM), q = p % (RT_TILE_DIM * RT_TILE_DIM);      // k counts across views
         uint32_t b = q / 64, l = q % 64;
         uint32_t px = (b % 4) * 8 + (l % 8), py = (b / 4) * 8 + (l / 8);
         at = ((size_t)k * RT_TILE_DIM * RT_TILE_DIM + py * RT_TILE_DIM + px) * bytes_per_pixel;
     } else {
         if (!inside) return;
-        at = ((size_t)row * F.width + col) * bytes_per_pixel;
+        at = (((size_t)view * F.height + row) * F.width + col) * bytes_per_pixel;
     }
     out[at] = rgb[0]; out[at + 1] = rgb[1]; out[at + 2] = rgb[2];
     if (bytes_per_pixel == 4) out[at + 3] = inside ? 255 : 0;
@@ -1661,9 +1664,9 @@ __global__ void rt_resolve(const DFrame F, uint8_t* out, uint32_t bytes_per_pixe
 __global__ void rt_resolve_aux(const DFrame F, uint32_t* prim, uint32_t* inst, uint8_t* flags) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= F.n_pixels) return;
-    uint32_t col, row;
-    if (!pixel_coords(F, p, col, row)) return;
-    size_t at = (size_t)row * F.width + col;
+    uint32_t view, col, row;
+    if (!pixel_coords(F, p, view, col, row)) return;
+    size_t at = ((size_t)view * F.height + row) * F.width + col;
     unsigned int fl = F.aux_flags[p];
     bool hit = fl & RT_FLAG_HIT;
     if (prim) prim[at] = hit ? F.aux_prim[p] : RT_PRIM_NONE;
@@ -1671,18 +1674,19 @@ __global__ void rt_resolve_aux(const DFrame F, uint32_t* prim, uint32_t* inst, u
     if (flags) flags[at] = (uint8_t)fl;
 }
 
-// Gathered shard buffers (rank-major, tile-major inside a rank) -> row-major frame.
-// One thread per frame pixel.
+// Gathered shard buffers (rank-major; inside a rank view-major, then tile-major) -> row-major frames, view after view.
+// One thread per pixel of every frame.
 __global__ void rt_assemble(const uint8_t* gathered, uint8_t* frame, uint32_t width, uint32_t height, uint32_t tiles_x,
-                            uint32_t shard_count, uint32_t tiles_per_shard, uint32_t bytes_per_pixel) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= width * height) return;
-    uint32_t row = i / width, col = i % width;
+                            uint32_t shard_count, uint32_t tiles_per_shard, uint32_t bytes_per_pixel, uint32_t n_views) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)width * height * n_views) return;
+    const uint32_t view = (uint32_t)(i / ((size_t)width * height)), j = (uint32_t)(i % ((size_t)width * height));
+    uint32_t row = j / width, col = j % width;
     uint32_t tile = (row / RT_TILE_DIM) * tiles_x + col / RT_TILE_DIM;
     uint32_t shard = tile % shard_count, k = tile / shard_count;
-    size_t src = (((size_t)shard * tiles_per_shard + k) * RT_TILE_DIM * RT_TILE_DIM +
+    size_t src = ((((size_t)shard * n_views + view) * tiles_per_shard + k) * RT_TILE_DIM * RT_TILE_DIM +
                   (row % RT_TILE_DIM) * RT_TILE_DIM + col % RT_TILE_DIM) * bytes_per_pixel;
-    size_t dst = (size_t)i * bytes_per_pixel;
+    size_t dst = i * bytes_per_pixel;
     for (uint32_t c = 0; c < bytes_per_pixel; ++c) frame[dst + c] = gathered[src + c];
 }
 
@@ -1705,8 +1709,8 @@ extern "C" int rt_query_traverse_blocks_per_cu(uint32_t n_seg, uint32_t stack_en
     return n;
 }
 
-extern "C" hipError_t rt_launch_generate(const DFrame* F, uint32_t blocks, hipStream_t stream) {
-    hipLaunchKernelGGL(rt_generate, dim3(blocks), dim3(RT_BLOCK_THREADS), 0, stream, *F);
+extern "C" hipError_t rt_launch_generate(const DFrame* F, const DViews* V, uint32_t blocks, hipStream_t stream) {
+    hipLaunchKernelGGL(rt_generate, dim3(blocks), dim3(RT_BLOCK_THREADS), 0, stream, *F, *V);
     return hipGetLastError();
 }
 
@@ -1761,9 +1765,9 @@ extern "C" hipError_t rt_launch_resolve_aux(const DFrame* F, uint32_t* prim, uin
 
 extern "C" hipError_t rt_launch_assemble(const uint8_t* gathered, uint8_t* frame, uint32_t width, uint32_t height,
                                          uint32_t tiles_x, uint32_t shard_count, uint32_t tiles_per_shard,
-                                         uint32_t bytes_per_pixel, hipStream_t stream) {
-    uint32_t n = width * height;
-    hipLaunchKernelGGL(rt_assemble, dim3((n + 255) / 256), dim3(256), 0, stream, gathered, frame, width, height, tiles_x,
-                       shard_count, tiles_per_shard, bytes_per_pixel);
+                                         uint32_t bytes_per_pixel, uint32_t n_views, hipStream_t stream) {
+    const size_t n = (size_t)width * height * n_views;
+    hipLaunchKernelGGL(rt_assemble, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, gathered, frame, width, height, tiles_x,
+                       shard_count, tiles_per_shard, bytes_per_pixel, n_views);
     return hipGetLastError();
 }

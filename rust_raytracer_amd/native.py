@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librt_hip.so")
 
 # every function include/rt_hip.h declares
-EXPORTS = ["rt_scene_create", "rt_scene_set_camera", "rt_render", "rt_render_device", "rt_shard_bytes",
+EXPORTS = ["rt_scene_create", "rt_scene_set_camera", "rt_scene_set_views", "rt_render", "rt_render_device", "rt_shard_bytes",
            "rt_assemble_shards", "rt_last_ray_counts", "rt_last_render_ms", "rt_last_trace_ms", "rt_set_kernel_timing",
            "rt_last_kernel_ms", "rt_scene_destroy",
            "rt_debug_set_queue_capacity", "rt_debug_last_regrown", "rt_last_error"]
@@ -66,6 +66,7 @@ def lib():
         vp, u32 = C.c_void_p, C.c_uint32
         L.rt_scene_create.argtypes = [C.POINTER(abi.RtSceneDesc), C.c_int, C.POINTER(vp)]
         L.rt_scene_set_camera.argtypes = [vp, C.POINTER(C.c_float), u32, u32]
+        L.rt_scene_set_views.argtypes = [vp, C.POINTER(C.c_float), u32, u32, u32]
         L.rt_render.argtypes = [vp, C.POINTER(abi.RtRenderParams), vp, C.POINTER(abi.RtAux)]
         L.rt_render_device.argtypes = [vp, C.POINTER(abi.RtRenderParams), vp]
         L.rt_shard_bytes.argtypes = [vp, C.POINTER(abi.RtRenderParams), C.POINTER(C.c_uint64)]
@@ -111,6 +112,7 @@ class DeviceScene:
         self._h = C.c_void_p()
         check(lib().rt_scene_create(C.byref(desc), device_id, C.byref(self._h)))
         self.width = self.height = 0
+        self.n_views = 1
 
     def close(self):
         if getattr(self, "_h", None):
@@ -126,24 +128,33 @@ class DeviceScene:
     def set_camera(self, screen_to_world, width: int, height: int):
         m = np.ascontiguousarray(np.asarray(screen_to_world, dtype=np.float32).reshape(16))
         check(lib().rt_scene_set_camera(self._h, m.ctypes.data_as(C.POINTER(C.c_float)), width, height))
-        self.width, self.height = width, height
+        self.width, self.height, self.n_views = width, height, 1
+
+    def set_views(self, screen_to_world, width: int, height: int):
+        """Several cameras rendered by one call (rt_scene_set_views): `screen_to_world` is [n_views, 16]; outputs gain
+        a leading view axis."""
+        m = np.ascontiguousarray(np.asarray(screen_to_world, dtype=np.float32).reshape(-1, 16))
+        check(lib().rt_scene_set_views(self._h, m.ctypes.data_as(C.POINTER(C.c_float)), m.shape[0], width, height))
+        self.width, self.height, self.n_views = width, height, m.shape[0]
 
     @staticmethod
     def _params(max_depth=10, fmt=abi.RT_FORMAT_RGB8, shard_index=0, shard_count=1, stream=None, mode=abi.RT_MODE_RAYTRACE):
         return abi.RtRenderParams(max_depth, fmt, shard_index, shard_count, mode, 0, stream)
 
     def render(self, max_depth: int = 10, channels: int = 3, aux: bool = False, depth_map: bool = False):
-        """Whole frame to host memory: dict(rgb[H,W,channels], counters, and with aux prim_id / instance_id / flags)."""
+        """Whole frame to host memory: dict(rgb[H,W,channels], counters, and with aux prim_id / instance_id / flags);
+        after set_views every array has a leading view axis."""
         h, w = self.height, self.width
-        rgb = np.zeros((h, w, channels), dtype=np.uint8)
+        lead = (self.n_views,) if self.n_views > 1 else ()
+        rgb = np.zeros(lead + (h, w, channels), dtype=np.uint8)
         p = self._params(max_depth, abi.RT_FORMAT_RGBA8 if channels == 4 else abi.RT_FORMAT_RGB8,
                          mode=abi.RT_MODE_DEPTH_MAP if depth_map else abi.RT_MODE_RAYTRACE)
         a = abi.RtAux()
         out = {"rgb": rgb}
         if aux:
-            out["prim_id"] = np.zeros((h, w), dtype=np.uint32)
-            out["instance_id"] = np.zeros((h, w), dtype=np.uint32)
-            out["flags"] = np.zeros((h, w), dtype=np.uint8)
+            out["prim_id"] = np.zeros(lead + (h, w), dtype=np.uint32)
+            out["instance_id"] = np.zeros(lead + (h, w), dtype=np.uint32)
+            out["flags"] = np.zeros(lead + (h, w), dtype=np.uint8)
             a.prim_id = out["prim_id"].ctypes.data_as(C.POINTER(C.c_uint32))
             a.instance_id = out["instance_id"].ctypes.data_as(C.POINTER(C.c_uint32))
             a.flags = out["flags"].ctypes.data_as(C.POINTER(C.c_uint8))
@@ -152,6 +163,7 @@ class DeviceScene:
         return out
 
     def shard_bytes(self, shard_count: int, channels: int = 3) -> int:
+        """Bytes of one view's shard (or frame when shard_count <= 1); a render writes n_views of them."""
         p = self._params(10, abi.RT_FORMAT_RGBA8 if channels == 4 else abi.RT_FORMAT_RGB8, 0, shard_count)
         n = C.c_uint64()
         check(lib().rt_shard_bytes(self._h, C.byref(p), C.byref(n)))

@@ -45,17 +45,19 @@ def extract_shard(frame: np.ndarray, shard_index: int, shard_count: int) -> np.n
     return out.reshape(-1)
 
 
-def assemble(gathered: np.ndarray, width: int, height: int, shard_count: int, channels: int = 3) -> np.ndarray:
-    """What rt_assemble_shards computes: rank-major gathered shard buffers -> frame [H, W, C]."""
+def assemble(gathered: np.ndarray, width: int, height: int, shard_count: int, channels: int = 3, views: int = 1) -> np.ndarray:
+    """What rt_assemble_shards computes: rank-major gathered shard buffers -> frame [H, W, C].  With several views
+    (rt_scene_set_views) a rank's buffer holds its shard of every view, view after view, and the result is
+    [views, H, W, C]."""
     tx, ty = tile_grid(width, height)
     n = tiles_per_shard(width, height, shard_count)
-    g = np.asarray(gathered).reshape(shard_count, n, T, T, channels)
-    frame = np.zeros((height, width, channels), dtype=g.dtype)
+    g = np.asarray(gathered).reshape(shard_count, views, n, T, T, channels)
+    frames = np.zeros((views, height, width, channels), dtype=g.dtype)
     for t in range(tx * ty):
         y0, x0 = (t // tx) * T, (t % tx) * T
         hh, ww = min(T, height - y0), min(T, width - x0)
-        frame[y0:y0 + hh, x0:x0 + ww] = g[t % shard_count, t // shard_count, :hh, :ww]
-    return frame
+        frames[:, y0:y0 + hh, x0:x0 + ww] = g[t % shard_count, :, t // shard_count, :hh, :ww]
+    return frames if views > 1 else frames[0]
 
 
 class ShardedFrame:
@@ -67,14 +69,15 @@ class ShardedFrame:
     defaults to torch.distributed.all_gather_into_tensor.
     """
 
-    def __init__(self, width, height, channels, rank, world_size, device, render_shard, assemble_fn, gather_fn=None):
+    def __init__(self, width, height, channels, rank, world_size, device, render_shard, assemble_fn, gather_fn=None,
+                 views=1):
         import torch
         self.torch = torch
         self.rank, self.world = rank, world_size
         self.width, self.height, self.channels = width, height, channels
-        nbytes = shard_bytes(width, height, world_size, channels)
+        nbytes = shard_bytes(width, height, world_size, channels) * views      # `views` frames travel together
         self.shard = torch.zeros(nbytes, dtype=torch.uint8, device=device)
-        self.frame = torch.zeros(height * width * channels, dtype=torch.uint8, device=device)
+        self.frame = torch.zeros(views * height * width * channels, dtype=torch.uint8, device=device)
         self.gathered = torch.zeros(nbytes * world_size, dtype=torch.uint8, device=device) if world_size > 1 else None
         self.render_shard, self.assemble_fn = render_shard, assemble_fn
         if gather_fn is None:

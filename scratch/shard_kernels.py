@@ -3,7 +3,7 @@ sys.path.insert(0, '/root/repo')
 import numpy as np, torch
 from rust_raytracer_amd import meshes, native
 md = meshes.ensure_model_dir()
-host = native.HostScene.load('/root/repo/scenes/reflective_bunnies.json', md)
+host = native.HostScene.load('/root/repo/scenes/%s.json' % (sys.argv[2] if len(sys.argv) > 2 else 'reflective_bunnies'), md)
 host.resize_screen(1920, 1080)
 dev = native.DeviceScene(host.desc(), 0)
 m, w, h = host.camera(); dev.set_camera(m, w, h)

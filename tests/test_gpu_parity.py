@@ -223,6 +223,53 @@ def test_tile_shards_assemble_to_the_same_frame(scenes_dir, model_dir, shards):
         dev.close()
 
 
+def test_views_rendered_together(scenes_dir, model_dir):
+    """rt_scene_set_views: five camera poses rendered by one call give, view by view, exactly what five calls with
+    rt_scene_set_camera give (pixels, ids, flags; ray counts add up), as shards too."""
+    import torch
+    from rust_raytracer_amd import synthetic
+    host = native.HostScene.load(os.path.join(scenes_dir, "reflective_bunnies.json"), model_dir)
+    host.resize_screen(333, 117)
+    dev = native.DeviceScene(host.desc(), 0)
+    try:
+        mats, single = [], []
+        for position, orientation in synthetic.orbit_poses(5, centre=(0.0, 0.0, -6.0)):
+            host.set_camera_pose(position, orientation)
+            m, w, h = host.camera()
+            mats.append(np.asarray(m, dtype=np.float32).reshape(16))
+            dev.set_camera(m, w, h)
+            single.append(dev.render(aux=True))
+        dev.set_views(np.stack(mats), w, h)
+        together = dev.render(aux=True)
+        assert together["rgb"].shape == (5, h, w, 3)
+        for v in range(5):
+            for key in ("rgb", "prim_id", "instance_id", "flags"):
+                assert np.array_equal(together[key][v], single[v][key]), (v, key)
+        assert together["counters"][:5].tolist() == sum(np.asarray(x["counters"][:5], dtype=np.int64) for x in single).tolist()
+        assert len({x["rgb"].tobytes() for x in single}) == 5                  # the poses do differ
+        # the same views as three shards: every rank's buffer holds its five shards, view after view
+        shards = 3
+        side = torch.cuda.Stream()
+        torch.cuda.set_stream(side)
+        nbytes = dev.shard_bytes(shards)
+        gathered = torch.zeros(shards * 5 * nbytes, dtype=torch.uint8, device="cuda")
+        for r in range(shards):
+            dev.render_device(gathered[r * 5 * nbytes:].data_ptr(), shard_index=r, shard_count=shards, stream=side.cuda_stream)
+            dev.last_ray_counts()
+        frames = torch.zeros(5 * h * w * 3, dtype=torch.uint8, device="cuda")
+        dev.assemble_shards(gathered.data_ptr(), frames.data_ptr(), shards, stream=side.cuda_stream)
+        full = torch.zeros(5 * h * w * 3, dtype=torch.uint8, device="cuda")
+        dev.render_device(full.data_ptr(), stream=side.cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(frames.cpu().numpy().reshape(5, h, w, 3), together["rgb"])
+        assert np.array_equal(full.cpu().numpy().reshape(5, h, w, 3), together["rgb"])
+        with pytest.raises(native.RtError):
+            dev.set_views(np.zeros((abi.RT_MAX_VIEWS + 1, 16), dtype=np.float32), w, h)
+    finally:
+        dev.close()
+        host.close()
+
+
 def test_kernel_timing_mode(scenes_dir, model_dir):
     """rt_set_kernel_timing / rt_last_kernel_ms: per-kernel HIP-event times of one frame, launch counts per depth,
     and no effect on the image."""

@@ -21,21 +21,21 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, width, height, channels, out_dir):
+def _worker(rank, world, port, width, height, channels, out_dir, views=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     rng = np.random.default_rng(1234)                      # every rank knows the whole reference frame
-    frame = rng.integers(0, 256, size=(height, width, channels), dtype=np.uint8)
+    frame = rng.integers(0, 256, size=(views, height, width, channels), dtype=np.uint8)
 
     def render_shard(out):
-        out.copy_(torch.from_numpy(sharding.extract_shard(frame, rank, world)))
+        out.copy_(torch.from_numpy(np.concatenate([sharding.extract_shard(frame[v], rank, world) for v in range(views)])))
 
     def assemble(gathered, out):
-        out.copy_(torch.from_numpy(sharding.assemble(gathered.numpy(), width, height, world, channels).reshape(-1)))
+        out.copy_(torch.from_numpy(sharding.assemble(gathered.numpy(), width, height, world, channels, views).reshape(-1)))
 
-    sf = sharding.ShardedFrame(width, height, channels, rank, world, "cpu", render_shard, assemble)
-    got = sf.step().numpy().reshape(height, width, channels)
+    sf = sharding.ShardedFrame(width, height, channels, rank, world, "cpu", render_shard, assemble, views=views)
+    got = sf.step().numpy().reshape(views, height, width, channels)
     np.save(os.path.join(out_dir, "rank%d.npy" % rank), got)
     ok = np.array_equal(got, frame)
     flag = torch.tensor([1 if ok else 0])
@@ -44,10 +44,10 @@ def _worker(rank, world, port, width, height, channels, out_dir):
     assert flag.item() == 1
 
 
-@pytest.mark.parametrize("width,height,channels", [(1920, 1080, 3), (333, 117, 4)])
-def test_two_ranks_assemble_the_frame(tmp_path, width, height, channels):
+@pytest.mark.parametrize("width,height,channels,views", [(1920, 1080, 3, 1), (333, 117, 4, 1), (333, 117, 3, 3)])
+def test_two_ranks_assemble_the_frame(tmp_path, width, height, channels, views):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), width, height, channels, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), width, height, channels, str(tmp_path), views), nprocs=world, join=True)
     a = np.load(tmp_path / "rank0.npy")
     b = np.load(tmp_path / "rank1.npy")
     assert np.array_equal(a, b)
