@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Throughput mode: a batch of camera views of one uploaded scene (256 poses on a circle around
 reflective_bunnies, 1920x1080 each).  View v is rendered by rank v % N; there is no collective on the data
-path - every rank keeps its frames in its own HBM.  One step = the whole batch.
+path - every rank keeps its frames in its own HBM.  One step = the whole batch.  A rank renders its views
+--views-per-pass at a time (rt_scene_set_views) and keeps --passes-in-flight passes queued, each on its own scene
+handle and stream.
 
     python bench_views.py --gpus 1 --views 256 --steps 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
@@ -29,6 +31,8 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--cpu-sample-views", type=int, default=4)
+    ap.add_argument("--views-per-pass", type=int, default=4)
+    ap.add_argument("--passes-in-flight", type=int, default=3)
     args = ap.parse_args()
 
     import numpy as np
@@ -51,17 +55,24 @@ def main():
     model_dir = meshes.ensure_model_dir(os.path.join("/tmp", "rust_raytracer_amd_models_rank%d_%d" % (rank, os.getuid())))
     host = native.HostScene.load(scene_path, model_dir)
     host.resize_screen(args.width, args.height)
-    dev = native.DeviceScene(host.desc(), local_rank)
     poses = synthetic.orbit_poses(args.views, centre=(0.0, 0.0, -6.0))
     mine = list(range(rank, args.views, world))
     cameras = []
     for v in mine:
         host.set_camera_pose(*poses[v])
         cameras.append(host.camera())
-    stream = torch.cuda.Stream()
-    torch.cuda.set_stream(stream)
-    handle = stream.cuda_stream
-    frames = torch.zeros((2, args.height * args.width * 3), dtype=torch.uint8, device="cuda")     # double buffer
+    per_pass = max(1, min(args.views_per_pass, len(mine) or 1))
+    depth = max(1, args.passes_in_flight)
+    devs = [native.DeviceScene(host.desc(), local_rank) for _ in range(depth)]
+    streams = [torch.cuda.Stream() for _ in range(depth)]
+    frames = torch.zeros((depth, per_pass * args.height * args.width * 3), dtype=torch.uint8, device="cuda")   # a pass's frames
+    dev, handle = devs[0], streams[0].cuda_stream
+    # the views of a pass; the last pass is filled up with its last view so that every pass has the same size
+    passes = []
+    for k in range(0, len(cameras), per_pass):
+        part = cameras[k:k + per_pass]
+        part = part + [part[-1]] * (per_pass - len(part))
+        passes.append(np.stack([np.asarray(m, dtype=np.float32).reshape(16) for m, _, _ in part]))
 
     def barrier():
         torch.cuda.synchronize()
@@ -71,22 +82,32 @@ def main():
 
     def batch(count_rays=False):
         total = np.zeros(5, dtype=np.int64)
-        for k, (m, w, h) in enumerate(cameras):
-            dev.set_camera(m, w, h)
-            dev.render_device(frames[k & 1].data_ptr(), stream=handle)
-            if count_rays:
+        if count_rays:                                 # view by view, so that the filled-up pass does not count twice
+            for m, w, h in cameras:
+                dev.set_camera(m, w, h)
+                dev.render_device(frames[0].data_ptr(), stream=handle)
                 total += dev.last_ray_counts()[:5].astype(np.int64)     # also raises if a ray list overflowed
+            return total
+        for k, mats in enumerate(passes):
+            s = k % depth
+            devs[s].set_views(mats, args.width, args.height)            # the matrices travel with the launch
+            devs[s].render_device(frames[s].data_ptr(), stream=streams[s].cuda_stream)
         return total
 
     rays = batch(count_rays=True)            # warm-up that also counts the batch's rays (deterministic per view)
-    for _ in range(max(args.warmup - 1, 0)):
+    for _ in range(max(args.warmup, 1)):
         batch()
+        torch.cuda.synchronize()
+    for d in devs:
+        d.last_ray_counts()                            # raises if a ray list overflowed
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         batch()
     barrier()
     elapsed = time.perf_counter() - t0
+    for d in devs:
+        d.last_ray_counts()
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     r = torch.tensor(rays, dtype=torch.int64, device="cuda")
@@ -103,6 +124,7 @@ def main():
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "orbit_views_%d" % args.views, "views": args.views, "width": args.width, "height": args.height,
                           "max_depth": 10, "rays_per_batch": int(rays[0]), "ms_per_view": elapsed / args.steps / max(len(mine), 1) * 1e3,
+                          "views_per_pass": per_pass, "passes_in_flight": depth,
                           "parallelism": "view v on rank v %% %d, no collective" % world}}
         if args.cpu_sample_views > 0 and world == 1:
             from oracle import orc
@@ -124,7 +146,8 @@ def main():
             out["cpu_baseline"] = {"value": cpu_rays / cpu_s / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
                                    "sample": "views %s of the batch, C++ oracle, %d threads" % (sample, cores)}
         print(json.dumps(out))
-    dev.close()
+    for d in devs:
+        d.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
