@@ -206,11 +206,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for k in range(max(-(-args.warmup // views), depth if args.warmup else 0)):
+    # Set-up, not warm-up: the first pass on a handle allocates its ray lists, the first gather creates the
+    # communicator, and a pass whose ray lists overflow is only noticed by the next one on that handle.
+    for s in every_slot:
+        for _ in range(2):
+            s.step()
+            torch.cuda.synchronize()
+    for k in range(-(-args.warmup // views)):          # the warm-up frames, in passes like the timed ones
         slots[k % depth].step()
-        torch.cuda.synchronize()      # a frame whose ray lists overflowed is noticed by the next one: let it finish
-    if last_slot and args.warmup:
-        last_slot.step()
     barrier()
     t0 = time.perf_counter()
     for k in range(passes):           # args.steps frames: `views` per pass ...
