@@ -3,7 +3,9 @@
 // A restatement of the reference's render path in C++ (the reference is Rust and cannot be built here).  Pinned by
 // the reference's own known answers (the intersection tests of raytracing/intersect_tests.rs, the hull and area
 // tests of bvh/hull.rs and geometry/aabb.rs) and by mesh-free crops of its committed render of og_scene_rust.json;
-// BVH traversal and instance transforms on meshes, for which the reference holds no fixture, are parity unpinned.
+// BVH traversal and instance transforms on meshes, for which the reference holds no fixture, are parity unpinned by
+// reference outputs; tests/test_oracle_bvh_property.py ties them to the pinned triangle test instead (the same triangles
+// as a mesh behind a BVH and an instance transform, and as free triangles, must give the same picture).
 #pragma once
 #include "orc_scene.h"
 
