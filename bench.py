@@ -174,11 +174,13 @@ def main():
         gathered.copy_(everyone)
 
     class Slot:
-        def __init__(self, views):
+        """One pass in flight: a scene handle (own ray lists), a stream and the buffers of `views` frames."""
+
+        def __init__(self, views, dev=None, stream=None):
             self.views = views
-            self.dev = native.DeviceScene(host.desc(), local_rank)
+            self.dev = dev or native.DeviceScene(host.desc(), local_rank)
             self.dev.set_views(np.tile(np.asarray(m, dtype=np.float32).reshape(1, 16), (views, 1)), w, h)
-            self.stream = torch.cuda.Stream()
+            self.stream = stream or torch.cuda.Stream()
             handle = self.stream.cuda_stream
             dev = self.dev
 
@@ -232,11 +234,7 @@ def main():
 
     # The same number of frames one at a time on one handle and one stream, for the latency of a single frame; the
     # per-kernel pass further down runs this way too, so that a launch's duration is its own.
-    dev.set_camera(m, w, h)
-    one = Slot.__new__(Slot)
-    one.dev, one.stream, one.views = dev, slots[0].stream, 1
-    one.sf = sharding.ShardedFrame(w, h, 3, rank, world, "cuda", slots[0].sf.render_shard, slots[0].sf.assemble_fn,
-                                   host_staged_gather if args.rehearse_on_one_gpu else None)
+    one = Slot(1, dev=dev, stream=slots[0].stream)       # slot 0's handle, from here on with a single view
     one.step(); one.step()
     barrier()
     t0 = time.perf_counter()
