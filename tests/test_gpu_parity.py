@@ -374,6 +374,14 @@ def test_api_errors(scenes_dir, model_dir):
         n = C.c_uint64()
         assert L.rt_shard_bytes(dev._h, C.byref(shard), C.byref(n)) == abi.RT_ERR_INVALID_ARGUMENT
         assert L.rt_render(dev._h, C.byref(p), None, None) == abi.RT_ERR_INVALID_ARGUMENT               # null canvas
+        # views: none, too many, and so many large ones that a pixel index would not fit a ray record
+        mats = np.tile(np.asarray(m, dtype=np.float32).reshape(1, 16), (abi.RT_MAX_VIEWS + 1, 1))
+        fp = mats.ctypes.data_as(C.POINTER(C.c_float))
+        assert L.rt_scene_set_views(dev._h, fp, 0, w, h) == abi.RT_ERR_INVALID_ARGUMENT
+        assert L.rt_scene_set_views(dev._h, fp, abi.RT_MAX_VIEWS + 1, w, h) == abi.RT_ERR_INVALID_ARGUMENT
+        assert L.rt_scene_set_views(dev._h, fp, 8, 4096, 4096) == 0
+        assert L.rt_shard_bytes(dev._h, C.byref(p), C.byref(n)) == abi.RT_ERR_INVALID_ARGUMENT and b"pixels" in L.rt_last_error()
+        dev.set_camera(m, w, h)
         assert L.rt_render(dev._h, C.byref(p), out.ctypes.data, None) == 0                                # and it still works
         assert out.any()
     finally:
