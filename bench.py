@@ -10,7 +10,7 @@ RCCL and every rank assembles the frame - the total work is fixed, so scaling is
         bench.py --gpus N --steps K --warmup W
 
 The timed frames are rendered the way a renderer with a queue of frames would: --views-per-pass frames travel through
-the recursion depths together (rt_scene_set_views; by default up to four whole frames' worth of pixels per rank), and a
+the recursion depths together (rt_scene_set_views; by default up to eight 1080p frames' worth of pixels per rank), and a
 rank keeps --frames-in-flight (default 3) such passes queued, each on its own scene handle and stream.  `value` is
 that rate; the "sequential" object of the JSON line is the rate with one frame at a time.
 
@@ -158,8 +158,9 @@ def main():
     # tables, the longest BVH walk - is paid once for all of them, which matters most for the small shards of many ranks.
     views = args.views_per_pass
     if views <= 0:
-        # as many as make four 1080p frames' worth of pixels per rank, leaving at least two passes to overlap
-        cap = max(1, min(abi.RT_MAX_VIEWS, 4 * 1920 * 1080 * world // (w * h)))
+        # as many as make eight 1080p frames' worth of pixels per rank (4: 9.7, 8: 10.4, 12: 10.3 Grays/s on one GPU),
+        # leaving at least two passes to overlap
+        cap = max(1, min(abi.RT_MAX_VIEWS, 8 * 1920 * 1080 * world // (w * h)))
         views = max([v for v in range(1, cap + 1) if args.steps // v >= 2] or [1])
     views = max(1, min(views, abi.RT_MAX_VIEWS, max(args.steps, 1)))
     passes, leftover = divmod(args.steps, views)       # the frames that do not fill a pass get a smaller pass of their own
