@@ -351,6 +351,34 @@ def test_degenerate_instance_takes_the_exact_path(tmp_path_factory):
     assert_parity(got, want, min_within_1=0.995)
 
 
+def test_native_app_writes_the_same_picture(scenes_dir, model_dir, tmp_path):
+    """tools/native_app.cpp - main.rs with paint_scene replaced by the C++ rt::HipRenderer of include/rt_renderer.hpp -
+    renders a scene file at its own screen_dimensions and writes the PNG the Python binding's render would."""
+    import subprocess
+    from PIL import Image
+    app = os.path.join(os.path.dirname(scenes_dir), "rust_raytracer_amd", "native_app")
+    scene = json.load(open(os.path.join(scenes_dir, "reflective_bunnies.json")))
+    scene["camera"]["screen_dimensions"] = [384, 216]
+    path = str(tmp_path / "small.json")
+    json.dump(scene, open(path, "w"))
+    out = str(tmp_path / "render.png")
+    r = subprocess.run([app, path, model_dir, out, "7"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "Parsing took" in r.stdout and "Rendering took" in r.stdout
+    host = native.HostScene.load(path, model_dir)
+    m, w, h = host.camera()
+    dev = native.DeviceScene(host.desc(), 0)
+    try:
+        dev.set_camera(m, w, h)
+        want = dev.render(max_depth=7)
+    finally:
+        dev.close()
+        host.close()
+    assert (w, h) == (384, 216)
+    assert np.array_equal(np.asarray(Image.open(out)), want["rgb"])
+    assert ("%d rays" % int(want["counters"][0])) in r.stdout
+
+
 def test_api_errors(scenes_dir, model_dir):
     """Argument validation of the C ABI: error codes with a message instead of the reference's panics."""
     import ctypes as C

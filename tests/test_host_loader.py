@@ -155,3 +155,21 @@ def test_write_png_roundtrip(tmp_path):
         assert back.shape == shape and np.array_equal(back, img)
     with pytest.raises(native.RtError):
         native.write_png(str(tmp_path / "no_such_dir" / "x.png"), np.zeros((2, 2, 3), dtype=np.uint8))
+
+
+NATIVE_APP = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rust_raytracer_amd", "native_app")
+
+
+def test_native_app_reports_errors(scenes_dir, tmp_path):
+    """tools/native_app.cpp (native_app/src/main.rs over rt::HipRenderer): where the reference panics, the tool
+    prints the library's message and exits with 1 - a scene file that does not exist, and, on a machine without
+    a GPU, the device."""
+    import subprocess
+    assert os.path.exists(NATIVE_APP), "build it with make -C rust_raytracer_amd/csrc"
+    r = subprocess.run([NATIVE_APP, str(tmp_path / "no_such_scene.json"), "", str(tmp_path / "x.png")], capture_output=True, text=True)
+    assert r.returncode == 1 and "no_such_scene.json" in r.stderr
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([NATIVE_APP, os.path.join(scenes_dir, "cornell_box.json"), "", str(tmp_path / "x.png")],
+                           capture_output=True, text=True)
+        assert r.returncode == 1 and "native_app:" in r.stderr and not os.path.exists(tmp_path / "x.png")

@@ -1,0 +1,38 @@
+// native_app on the HIP path: what native_app/src/main.rs does - parse a scene file, paint it, write a PNG, print the
+// two durations - with paint_scene (main.rs:46-66) replaced by rt::HipRenderer.  The reference's three paths are
+// constants (main.rs:17-23); here they are arguments with the same defaults.
+//
+//     native_app [scene.json [model_dir [image.png [max_depth]]]]
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "../include/rt_renderer.hpp"
+
+int main(int argc, char** argv) {
+    const std::string scene_path = argc > 1 ? argv[1] : "res/scenes/og_scene_rust.json";
+    const std::string model_dir = argc > 2 ? argv[2] : "res/models";
+    const std::string image_path = argc > 3 ? argv[3] : "render.png";
+    const uint32_t max_depth = argc > 4 ? (uint32_t)std::atoi(argv[4]) : RT_DEFAULT_MAX_DEPTH;
+    using clock = std::chrono::steady_clock;
+    try {
+        auto t0 = clock::now();
+        rt::HipRenderer renderer(0, 0, scene_path, model_dir);              // the scene file's own screen_dimensions
+        renderer.set_max_depth(max_depth);
+        std::printf("Parsing took %.3fs\n", std::chrono::duration<float>(clock::now() - t0).count());
+
+        std::vector<uint8_t> canvas((size_t)renderer.width() * renderer.height() * 3);
+        t0 = clock::now();
+        renderer.render_rgb(canvas.data(), canvas.size());
+        std::printf("Rendering took %.3fs\n", std::chrono::duration<float>(clock::now() - t0).count());
+        std::printf("%llu rays, %.3f ms on the device\n", (unsigned long long)renderer.last_rays(), renderer.last_render_ms());
+
+        rt::check(rt_host_write_png(image_path.c_str(), canvas.data(), renderer.width(), renderer.height(), 3));
+    } catch (const rt::Error& e) {
+        std::fprintf(stderr, "native_app: %s (code %d)\n", e.what(), e.code);   // the reference panics here
+        return 1;
+    }
+    return 0;
+}
