@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--cpu-sample-views", type=int, default=4)
-    ap.add_argument("--views-per-pass", type=int, default=4)
+    ap.add_argument("--views-per-pass", type=int, default=8)
     ap.add_argument("--passes-in-flight", type=int, default=3)
     args = ap.parse_args()
 
@@ -67,12 +67,9 @@ def main():
     streams = [torch.cuda.Stream() for _ in range(depth)]
     frames = torch.zeros((depth, per_pass * args.height * args.width * 3), dtype=torch.uint8, device="cuda")   # a pass's frames
     dev, handle = devs[0], streams[0].cuda_stream
-    # the views of a pass; the last pass is filled up with its last view so that every pass has the same size
-    passes = []
-    for k in range(0, len(cameras), per_pass):
-        part = cameras[k:k + per_pass]
-        part = part + [part[-1]] * (per_pass - len(part))
-        passes.append(np.stack([np.asarray(m, dtype=np.float32).reshape(16) for m, _, _ in part]))
+    # the views of a pass (the last pass may hold fewer: a handle's buffers serve any smaller number of views)
+    passes = [np.stack([np.asarray(m, dtype=np.float32).reshape(16) for m, _, _ in cameras[k:k + per_pass]])
+              for k in range(0, len(cameras), per_pass)]
 
     def barrier():
         torch.cuda.synchronize()
@@ -82,16 +79,12 @@ def main():
 
     def batch(count_rays=False):
         total = np.zeros(5, dtype=np.int64)
-        if count_rays:                                 # view by view, so that the filled-up pass does not count twice
-            for m, w, h in cameras:
-                dev.set_camera(m, w, h)
-                dev.render_device(frames[0].data_ptr(), stream=handle)
-                total += dev.last_ray_counts()[:5].astype(np.int64)     # also raises if a ray list overflowed
-            return total
         for k, mats in enumerate(passes):
             s = k % depth
             devs[s].set_views(mats, args.width, args.height)            # the matrices travel with the launch
             devs[s].render_device(frames[s].data_ptr(), stream=streams[s].cuda_stream)
+            if count_rays:
+                total += devs[s].last_ray_counts()[:5].astype(np.int64)  # waits; also raises if a ray list overflowed
         return total
 
     rays = batch(count_rays=True)            # warm-up that also counts the batch's rays (deterministic per view)

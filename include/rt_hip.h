@@ -231,6 +231,8 @@ int rt_scene_set_camera(RtScene* scene, const float screen_to_world[16], uint32_
  * writes n_views frames; the ray counts and times are those of all views together.  The views travel through every
  * recursion depth together, so the fixed cost of a depth (launches, the longest BVH walk) is paid once for all of
  * them: small frames and shards render markedly faster per view this way.  rt_scene_set_camera is the case n_views = 1.
+ * A handle keeps the buffers of the largest frame it has rendered, so going back and forth between view counts
+ * (a last, smaller pass of a batch) allocates nothing.
  * The reference has no counterpart: its renderers draw one camera per call (gpu_renderer.rs:280, main.rs:46-66);
  * a caller with a queue of frames (an animation, the batch of orbit views) would loop over it. */
 #define RT_MAX_VIEWS 32

@@ -263,6 +263,13 @@ def test_views_rendered_together(scenes_dir, model_dir):
         torch.cuda.synchronize()
         assert np.array_equal(frames.cpu().numpy().reshape(5, h, w, 3), together["rgb"])
         assert np.array_equal(full.cpu().numpy().reshape(5, h, w, 3), together["rgb"])
+        # fewer views on the same handle (its buffers, made for five, stay), then one, then five again
+        for n in (2, 1, 5):
+            dev.set_views(np.stack(mats[5 - n:]), w, h)
+            part = dev.render(aux=True)
+            for key in ("rgb", "prim_id", "instance_id", "flags"):
+                got = part[key].reshape((n,) + single[0][key].shape)
+                assert all(np.array_equal(got[v], single[5 - n + v][key]) for v in range(n)), (n, key)
         with pytest.raises(native.RtError):
             dev.set_views(np.zeros((abi.RT_MAX_VIEWS + 1, 16), dtype=np.float32), w, h)
     finally:
