@@ -61,7 +61,7 @@ def algorithmic_work(counters, width, height):
     return {"bytes": nbytes, "flops": flops, "walk_bytes": walk_bytes, "walk_flops": walk_flops}
 
 
-def cpu_baseline(scene_path, model_dir, width, height, max_depth, budget_s=12.0):
+def cpu_baseline(scene_path, model_dir, width, height, max_depth, budget_s=15.0):
     """The CPU oracle (C++ restatement of the reference renderer, row-parallel like native_app's
     rayon loop) timed on this host; also returns its un-pruned traversal statistics."""
     from oracle import orc
@@ -73,7 +73,7 @@ def cpu_baseline(scene_path, model_dir, width, height, max_depth, budget_s=12.0)
     dt = time.perf_counter() - t0
     frames, total = 1, dt
     best = dt
-    while total + best < budget_s and frames < 8:
+    while total + best < budget_s and frames < 32:
         t0 = time.perf_counter()
         s.render(max_depth, threads=cores, aux=False)
         d = time.perf_counter() - t0
