@@ -69,6 +69,31 @@ public:
         push_camera();
     }
 
+    // Several frames in one call (rt_scene_set_views): `n` camera drags, each applied to the camera the previous one
+    // left (turn_camera semantics, scene.rs:60-97), one RGB8 frame per drag, back to back in `canvases`
+    // (n * width * height * 3 bytes).  An orbit of n frames costs markedly less this way than n calls of render_rgb.
+    // The reference has no counterpart: its loop would call turn_camera and render n times.
+    void render_drags_rgb(const float (*drags)[4], uint32_t n, uint8_t* canvases, size_t canvases_len) {
+        if (n == 0 || n > RT_MAX_VIEWS) throw Error(RT_ERR_INVALID_ARGUMENT, "between 1 and " + std::to_string(RT_MAX_VIEWS) + " frames per call");
+        if (canvases_len != (size_t)n * width_ * height_ * 3)
+            throw Error(RT_ERR_INVALID_ARGUMENT, "canvases of " + std::to_string(canvases_len) + " bytes for " + std::to_string(n) + " frames");
+        std::vector<float> views((size_t)n * 16);
+        for (uint32_t k = 0; k < n; ++k) {
+            check(rt_host_scene_turn_camera(host_, drags[k][0], drags[k][1], drags[k][2], drags[k][3]));
+            check(rt_host_scene_camera(host_, &views[(size_t)k * 16], &width_, &height_));
+        }
+        check(rt_scene_set_views(scene_, views.data(), n, width_, height_));
+        RtRenderParams p{};
+        p.max_depth = max_depth_;
+        p.output_format = RT_FORMAT_RGB8;
+        p.shard_count = 1;
+        RtAux aux{};
+        check(rt_render(scene_, &p, canvases, &aux));
+        last_rays_ = aux.counters[RT_CTR_RAYS];
+        check(rt_last_render_ms(scene_, &last_ms_));
+        push_camera();                                     // back to one view: the camera after the last drag
+    }
+
     // MAX_RAY_RECURSION_DEPTH (raytracer.rs:9) is a constant of the reference; here it can be set per renderer.
     void set_max_depth(uint32_t depth) { max_depth_ = depth; }
     // primary + secondary rays and kernel milliseconds of the last render

@@ -369,7 +369,7 @@ def test_native_app_writes_the_same_picture(scenes_dir, model_dir, tmp_path):
     path = str(tmp_path / "small.json")
     json.dump(scene, open(path, "w"))
     out = str(tmp_path / "render.png")
-    r = subprocess.run([app, path, model_dir, out, "7"], capture_output=True, text=True, timeout=120)
+    r = subprocess.run([app, path, model_dir, out, "7", "3"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     assert "Parsing took" in r.stdout and "Rendering took" in r.stdout
     host = native.HostScene.load(path, model_dir)
@@ -378,12 +378,18 @@ def test_native_app_writes_the_same_picture(scenes_dir, model_dir, tmp_path):
     try:
         dev.set_camera(m, w, h)
         want = dev.render(max_depth=7)
+        assert (w, h) == (384, 216)
+        assert np.array_equal(np.asarray(Image.open(out)), want["rgb"])
+        assert ("%d rays" % int(want["counters"][0])) in r.stdout
+        # the three further frames (rt::HipRenderer::render_drags_rgb: one call, three views) against one render each
+        for k in range(3):
+            host.turn_camera(0.0, 0.0, 40.0, 0.0)
+            m, w, h = host.camera()
+            dev.set_camera(m, w, h)
+            assert np.array_equal(np.asarray(Image.open("%s.%d.png" % (out, k))), dev.render(max_depth=7)["rgb"]), k
     finally:
         dev.close()
         host.close()
-    assert (w, h) == (384, 216)
-    assert np.array_equal(np.asarray(Image.open(out)), want["rgb"])
-    assert ("%d rays" % int(want["counters"][0])) in r.stdout
 
 
 def test_api_errors(scenes_dir, model_dir):

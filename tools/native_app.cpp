@@ -2,7 +2,7 @@
 // two durations - with paint_scene (main.rs:46-66) replaced by rt::HipRenderer.  The reference's three paths are
 // constants (main.rs:17-23); here they are arguments with the same defaults.
 //
-//     native_app [scene.json [model_dir [image.png [max_depth]]]]
+//     native_app [scene.json [model_dir [image.png [max_depth [n_orbit]]]]]
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -30,6 +30,21 @@ int main(int argc, char** argv) {
         std::printf("%llu rays, %.3f ms on the device\n", (unsigned long long)renderer.last_rays(), renderer.last_render_ms());
 
         rt::check(rt_host_write_png(image_path.c_str(), canvas.data(), renderer.width(), renderer.height(), 3));
+
+        // native_app [...] max_depth n_orbit: n_orbit more frames, the camera dragged 40 pixels to the right before each,
+        // rendered in one call and written next to the first as <image>.<k>.png
+        const uint32_t n_orbit = argc > 5 ? (uint32_t)std::atoi(argv[5]) : 0;
+        if (n_orbit) {
+            std::vector<float> drags((size_t)n_orbit * 4);
+            for (uint32_t k = 0; k < n_orbit; ++k) { drags[4 * k] = 0.0f; drags[4 * k + 1] = 0.0f; drags[4 * k + 2] = 40.0f; drags[4 * k + 3] = 0.0f; }
+            std::vector<uint8_t> frames((size_t)n_orbit * canvas.size());
+            t0 = clock::now();
+            renderer.render_drags_rgb(reinterpret_cast<const float(*)[4]>(drags.data()), n_orbit, frames.data(), frames.size());
+            std::printf("Rendering %u more frames took %.3fs\n", n_orbit, std::chrono::duration<float>(clock::now() - t0).count());
+            for (uint32_t k = 0; k < n_orbit; ++k)
+                rt::check(rt_host_write_png((image_path + "." + std::to_string(k) + ".png").c_str(), frames.data() + (size_t)k * canvas.size(),
+                                            renderer.width(), renderer.height(), 3));
+        }
     } catch (const rt::Error& e) {
         std::fprintf(stderr, "native_app: %s (code %d)\n", e.what(), e.code);   // the reference panics here
         return 1;
