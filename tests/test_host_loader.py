@@ -173,3 +173,26 @@ def test_native_app_reports_errors(scenes_dir, tmp_path):
         r = subprocess.run([NATIVE_APP, os.path.join(scenes_dir, "cornell_box.json"), "", str(tmp_path / "x.png")],
                            capture_output=True, text=True)
         assert r.returncode == 1 and "native_app:" in r.stderr and not os.path.exists(tmp_path / "x.png")
+
+
+REFERENCE = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE, "res", "models")), reason="the reference checkout is not on this machine")
+def test_reference_own_mesh_files():
+    """The one scene of the reference whose mesh file is in its repository (og_scene_bvh_comparison.json with
+    res/models/sphere_high.obj, a file with quads): read in place, never copied.  Both loaders must produce the same
+    arrays, and the triangle count after tobj's fan triangulation is the known 22 200."""
+    path = os.path.join(REFERENCE, "res", "scenes", "og_scene_bvh_comparison.json")
+    models = os.path.join(REFERENCE, "res", "models")
+    mine = native.HostScene.load(path, models)
+    ref = orc.OracleScene.from_file(path, models)
+    assert mine.desc().n_mesh_triangles == 22200 and ref.desc().n_mesh_triangles == 22200
+    a, b = abi.desc_arrays(mine.desc()), abi.desc_arrays(ref.desc())
+    for key, typ in TYPES.items():
+        x, y = as_numeric(a[key], typ), as_numeric(b[key], typ)
+        for field in x:
+            assert np.array_equal(x[field], y[field]), (key, field)
+    nodes = as_numeric(a["mesh_bvh_nodes"], abi.RtBvhNode)
+    leaves = nodes["is_leaf"] != 0
+    assert nodes["triangle_count"][leaves].sum() == 22200 and nodes["triangle_count"][leaves].max() <= 5
