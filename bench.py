@@ -30,6 +30,9 @@ sys.path.insert(0, ROOT)
 WORKLOADS = {
     # name: scene file, width, height, max_depth
     "reflective_bunnies_1080p": ("reflective_bunnies.json", 1920, 1080, 10),
+    # the same with the bunny replaced by a sphere of the size and triangle count of the reference's res/models/sphere_high.obj
+    # (an icosphere of radius 0.5, 20 480 triangles): a second stand-in for the bunny.obj the reference does not ship
+    "reflective_bunnies_1080p_sphere_standin": ("reflective_bunnies.json", 1920, 1080, 10),
     "cornell_box_720p": ("cornell_box.json", 1280, 720, 10),
     "mirror_sphere_1080p_depth16": ("mirror_sphere.json", 1920, 1080, 16),
     "infinity_santa_1080p_depth16": ("infinity_santa.json", 1920, 1080, 16),
@@ -141,7 +144,12 @@ def main():
             fh.write(synthetic.instance_grid_scene(model_dir, int(opts["grid"]), int(opts["meshes"]), int(opts["level"]), width, height))
     else:
         scene_path = os.path.join(ROOT, "scenes", scene_file)
-        if model_dir is None:
+        if model_dir is None and args.workload.endswith("_sphere_standin"):
+            model_dir = os.path.join("/tmp", "rust_raytracer_amd_sphere_models_rank%d_%d" % (rank, os.getuid()))
+            os.makedirs(model_dir, exist_ok=True)
+            with open(os.path.join(model_dir, "bunny.obj"), "w") as fh:
+                fh.write(meshes.obj_text(*meshes.uv_sphere(5)))
+        elif model_dir is None:
             model_dir = meshes.ensure_model_dir(os.path.join("/tmp", "rust_raytracer_amd_models_rank%d_%d" % (rank, os.getuid())))
 
     host = native.HostScene.load(scene_path, model_dir)
