@@ -934,6 +934,20 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_setup_slow(const DScene S
         const float o_l1 = fabsf(r.o.x) + fabsf(r.o.y) + fabsf(r.o.z);
         bool exact_mesh = false;             // exact path: the winner so far is a mesh triangle
         float ex_t = 0.0f, ex_u = 0.0f, ex_v = 0.0f; uint32_t ex_slot = 0, ex_inst = 0;
+        // A candidate with t = NaN (a local ray with a NaN direction, as a singular instance matrix makes it) is only
+        // taken when nothing was found before it and then blocks everything after it (utils/mod.rs:17): what it does
+        // depends on the outcome of the instances before it.  So a ray with one such instance walks all of them here,
+        // one after the other in Vec order; only rays whose local rays are all finite leave their walks to rt_traverse.
+        bool all_here = !ray_finite;
+        if (active && ray_finite && !settled)
+            for (uint32_t ii = 0; ii < S.n_instances; ++ii) {
+                const DInstance& inst = S.instances[ii];
+                if (inst.root_ref == RT_REF_NONE) continue;
+                const V3 lo = transform34(inst.model_inverse, r.o);
+                const V3 dv = transform34(inst.rotation_scale_inverse, r.d);
+                const float dn = sqrtf(dot3(dv, dv));
+                if (!(finite3(lo) && finite3(mk(dv.x / dn, dv.y / dn, dv.z / dn)))) all_here = true;
+            }
         for (uint32_t ii = 0; ii < S.n_instances; ++ii) {
             const DInstance& inst = S.instances[ii];
             bool want_item = false;
@@ -943,8 +957,7 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_setup_slow(const DScene S
                 V3 dv = transform34(inst.rotation_scale_inverse, r.d);
                 float dn = sqrtf(dot3(dv, dv));
                 lr.d = mk(dv.x / dn, dv.y / dn, dv.z / dn);                 // glm::normalize, intersect.rs:304-308
-                const bool lr_finite = ray_finite && finite3(lr.o) && finite3(lr.d);
-                if (!lr_finite) {
+                if (all_here) {
                     // reference order, to the end, right here
                     bool m_have; float m_t, m_u, m_v; uint32_t m_slot;
                     exact_mesh_hit(S, inst.root_ref, lr, m_have, m_t, m_u, m_v, m_slot);

@@ -171,3 +171,46 @@ def random_scene(model_dir: str, seed: int, width: int = 96, height: int = 64) -
         "mesh_instances": instances,
     }
     return json.dumps(scene)
+
+
+def spoiled_scene(model_dir: str, seed: int, width: int = 96, height: int = 64):
+    """random_scene(seed) spoiled on purpose, for fuzzing the corners where the reference's arithmetic runs into ties,
+    zeros, infinities and NaN: exact duplicates of an instance, a sphere, a plane (equal t: the earlier one in the
+    Vec wins, utils/mod.rs:17), an instance scaled to zero along an axis (singular matrices, NaN local rays), a sphere
+    of radius zero, a plane with a zero normal, a triangle with two equal vertices, a light at the camera position.
+    Returns (scene JSON, list of what was done)."""
+    import copy
+    import random
+    rng = random.Random(seed ^ 0x5F3759DF)
+    scene = json.loads(random_scene(model_dir, seed, width, height))
+    done = []
+    instances = scene["mesh_instances"]
+    if instances and rng.random() < 0.5:
+        dup = copy.deepcopy(rng.choice(instances))
+        if rng.random() < 0.5:
+            dup.pop("material_override", None)
+        instances.insert(rng.randrange(len(instances) + 1), dup)
+        done.append("duplicate instance")
+    if instances and rng.random() < 0.3:
+        rng.choice(instances)["scale"][rng.choice("xyz")] = 0.0
+        done.append("zero scale")
+    if scene["spheres"] and rng.random() < 0.4:
+        scene["spheres"].append(copy.deepcopy(scene["spheres"][0]))
+        done.append("duplicate sphere")
+    if scene["spheres"] and rng.random() < 0.2:
+        scene["spheres"][-1]["radius"] = 0.0
+        done.append("zero radius")
+    if scene["planes"] and rng.random() < 0.4:
+        scene["planes"].append(copy.deepcopy(scene["planes"][0]))
+        done.append("duplicate plane")
+    if scene["planes"] and rng.random() < 0.15:
+        scene["planes"][-1]["normal"] = _xyz(0.0, 0.0, 0.0)
+        done.append("zero normal")
+    if scene["triangles"] and rng.random() < 0.3:
+        scene["triangles"][0]["vertices"][1] = copy.deepcopy(scene["triangles"][0]["vertices"][0])
+        done.append("collapsed triangle")
+    if scene["lights"] and rng.random() < 0.2:
+        p = scene["camera"]["position"]
+        scene["lights"][0]["position"] = {"x": p["x"], "y": p["y"], "z": p["z"], "w": 1}
+        done.append("light at the camera")
+    return json.dumps(scene), done

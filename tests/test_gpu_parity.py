@@ -345,6 +345,25 @@ def test_random_scenes(tmp_path_factory, block):
             raise AssertionError("seed %d: %s" % (seed, e))
 
 
+@pytest.mark.parametrize("block", range(3))
+def test_spoiled_random_scenes(tmp_path_factory, block):
+    """The fuzz scenes spoiled on purpose (synthetic.spoiled_scene): duplicated instances, spheres and planes (ties in t
+    go to the earlier one), singular instance matrices (a NaN candidate is only taken when nothing came before it, and
+    then blocks what comes after), zero radius, zero normals, collapsed triangles, a light at the camera."""
+    from rust_raytracer_amd import synthetic
+    d = str(tmp_path_factory.mktemp("spoiled_models"))
+    seen = set()
+    for seed in range(block * 40, block * 40 + 40):
+        text, what = synthetic.spoiled_scene(d, seed)
+        seen.update(what)
+        got, want = render_both(orc.OracleScene.from_text(text, d), max_depth=5)
+        try:
+            assert_parity(got, want, min_within_1=0.99)
+        except AssertionError as e:
+            raise AssertionError("seed %d %s: %s" % (seed, what, e))
+    assert {"duplicate instance", "zero scale", "duplicate sphere", "duplicate plane"} <= seen
+
+
 def test_degenerate_instance_takes_the_exact_path(tmp_path_factory):
     """An instance scaled to zero along one axis: its inverse matrices are what glm::inverse makes of a singular
     matrix, no culling box can be trusted, and the local rays have NaN directions.  Every ray then goes through
