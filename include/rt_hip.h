@@ -260,7 +260,9 @@ int rt_shard_bytes(const RtScene* scene, const RtRenderParams* params, uint64_t*
 int rt_assemble_shards(RtScene* scene, const RtRenderParams* params, const void* d_gathered, void* d_frame);
 
 /* Ray counts of the last rt_render / rt_render_device on this handle (waits for it to finish).
- * Fills RT_CTR_RAYS..RT_CTR_TRANSMITTED. */
+ * Fills RT_CTR_RAYS..RT_CTR_TRANSMITTED.  Fails with RT_ERR_OUT_OF_RANGE if a ray list overflowed in any
+ * rt_render_device frame since the previous call of this function (such a frame's output is incomplete); every
+ * overflow is reported once. */
 int rt_last_ray_counts(RtScene* scene, uint64_t counters[RT_N_COUNTERS]);
 
 /* Time of the last rt_render / rt_render_device on this handle between its first and last

@@ -9,7 +9,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "rt_device.h"
@@ -54,10 +56,15 @@ struct RtScene {
     int n_cus = 0;
     uint32_t list_blocks = 0;           // grid of the list-producing kernels
     uint32_t traverse_blocks = 0;       // grid of the BVH walk
-    unsigned int* h_overflow = nullptr; // host-mapped flag the kernels set when a list does not fit
+    // Host-mapped word into which the kernels store the sequence number of a frame whose lists did not fit.  The host
+    // never writes it: what it has seen so far is `overflow_seen`, what it has not yet told the caller `overflow_unreported`.
+    volatile unsigned int* h_overflow = nullptr;
     unsigned int* d_overflow = nullptr;
+    uint32_t frame_seq = 0;             // sequence number of the last frame enqueued on this handle
+    uint32_t overflow_seen = 0;
+    bool overflow_unreported = false;
     uint32_t capacity_shift = 0;        // lists are (default capacity << capacity_shift) rays long
-    bool must_grow = false;             // the last frame overflowed: the next one needs lists longer than it had
+    bool must_grow = false;             // a frame overflowed: the next one needs lists longer than it had
     uint32_t regrown = 0;               // times rt_render had to enlarge the lists for its last frame
     std::vector<void*> scene_allocs;
     DScene d{};
@@ -68,6 +75,8 @@ struct RtScene {
     // per-frame buffers, reallocated when the key below changes
     struct FrameKey { uint32_t w = 0, h = 0, shard_count = 0, max_depth = 0, aux = 0, blocks = 0, capacity = 0, debug = 0; } key;
     DFrame f{};
+    DFrame last_f{};                    // the frame enqueued last (its statistics are what rt_last_ray_counts reads)
+    size_t last_stats_words = 0;
     std::vector<void*> frame_allocs;
     uint8_t* d_pixels = nullptr;        // staging for rt_render
     size_t d_pixels_bytes = 0;
@@ -435,7 +444,7 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device_id, RtScene**
     if (const char* env = getenv("RT_BLOCKS_PER_CU")) { int v = atoi(env); if (v >= 1 && v <= bpc) bpc = v; }
     s->traverse_blocks = (uint32_t)(s->n_cus * bpc);
     if (hipHostMalloc((void**)&s->h_overflow, sizeof(unsigned int), hipHostMallocMapped) != hipSuccess ||
-        hipHostGetDevicePointer((void**)&s->d_overflow, s->h_overflow, 0) != hipSuccess)
+        hipHostGetDevicePointer((void**)&s->d_overflow, const_cast<unsigned int*>(s->h_overflow), 0) != hipSuccess)
         return bail(fail(RT_ERR_DEVICE, "cannot allocate the host-visible overflow flag"));
     *s->h_overflow = 0;
     *out_scene = s;
@@ -453,7 +462,7 @@ extern "C" void rt_scene_destroy(RtScene* s) {
     if (s->d_aux_prim_out) (void)hipFree(s->d_aux_prim_out);
     if (s->d_aux_inst_out) (void)hipFree(s->d_aux_inst_out);
     if (s->d_aux_flags_out) (void)hipFree(s->d_aux_flags_out);
-    if (s->h_overflow) (void)hipHostFree(s->h_overflow);
+    if (s->h_overflow) (void)hipHostFree(const_cast<unsigned int*>(s->h_overflow));
     for (hipEvent_t e : s->marks) (void)hipEventDestroy(e);
     if (s->ev_start) (void)hipEventDestroy(s->ev_start);
     if (s->ev_stop) (void)hipEventDestroy(s->ev_stop);
@@ -505,16 +514,76 @@ static int frame_geometry(const RtScene* s, const RtRenderParams* p, bool sharde
     return RT_OK;
 }
 
-template <class T>
-static int frame_alloc(RtScene* s, size_t count, T** out) {
-    void* p = nullptr;
-    HIP_TRY(hipMalloc(&p, count * sizeof(T)));
-    s->frame_allocs.push_back(p);
-    *out = static_cast<T*>(p);
+static uint32_t ceil_div(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+// What a frame's buffers hold besides the pointers in DFrame.
+struct FrameSizes { size_t pixel_clear_bytes = 0, counter_words = 0, stats_words = 0; };
+
+// Lays out the per-frame buffers of DFrame for `n_pixels` local pixels, lists of `capacity` rays per recursion depth cut
+// into `blocks` producer segments (none shorter than seg_min) plus the shared overflow segment.  Memory comes from
+// `take(bytes, &ptr)`, which returns RT_OK or an error code: hipMalloc for the handle's own buffers.
+template <class Take>
+static int carve_frame(uint32_t n_pixels, uint32_t n_lights, uint32_t blocks, uint64_t capacity, uint32_t seg_min, bool aux,
+                       Take&& take, DFrame* out, FrameSizes* sz) {
+    DFrame& f = *out;
+    memset(&f, 0, sizeof(f));
+    f.n_seg = blocks + 1;
+    auto seg = [&](uint64_t total) { return std::max<uint32_t>(ceil_div(total, blocks), seg_min); };
+    f.seg_rays = seg(capacity);          f.ovf_rays = (uint32_t)(capacity / 4 + 1024);
+    f.seg_items = seg(capacity);         f.ovf_items = (uint32_t)(capacity / 4 + 1024);
+    f.seg_fat = seg(capacity / 2);       f.ovf_fat = (uint32_t)(capacity / 8 + 1024);
+    f.seg_hits = seg(capacity / 2);      f.ovf_hits = (uint32_t)(capacity / 8 + 1024);
+    const size_t ray_slots = (size_t)blocks * f.seg_rays + f.ovf_rays;
+    const size_t item_slots = (size_t)blocks * f.seg_items + f.ovf_items;
+    const size_t fat_slots = (size_t)blocks * f.seg_fat + f.ovf_fat;
+    const size_t hit_slots = (size_t)blocks * f.seg_hits + f.ovf_hits;
+    const size_t all_ray_slots = ray_slots + hit_slots * n_lights;      // + the shadow rays, see DFrame::rays
+    if (all_ray_slots >= RT_META_RAY_LIMIT) return fail(RT_ERR_OUT_OF_RANGE, "a frame needs more than 2^31 ray slots per depth");
+    sz->stats_words = (size_t)blocks * 4 * 8;
+    // colour sums and poison words in one allocation, all counters in another: two clears per frame
+    sz->pixel_clear_bytes = (size_t)3 * n_pixels * sizeof(long long) + (size_t)n_pixels * sizeof(unsigned int);
+    sz->counter_words = 7 * (size_t)f.n_seg + 2 * (RT_MAX_DEPTH_LIMIT + 2) + sz->stats_words;
+    unsigned int* counters = nullptr;
+    int rc;
+    auto get = [&](size_t count, auto** p) {
+        void* v = nullptr;
+        int r = take(count * sizeof(**p), &v);
+        *p = static_cast<std::remove_reference_t<decltype(*p)>>(v);
+        return r;
+    };
+    if ((rc = get(sz->pixel_clear_bytes / sizeof(long long) + 1, &f.acc)) || (rc = get(sz->counter_words, &counters)) ||
+        (rc = get((size_t)3 * n_pixels, &f.acc_big)) ||
+        (rc = get(2 * all_ray_slots, &f.rays[0])) || (rc = get(2 * all_ray_slots, &f.rays[1])) ||
+        (rc = get(all_ray_slots, &f.best)) ||
+        (rc = get(item_slots, &f.items)) || (rc = get(item_slots, &f.item_results)) ||
+        (rc = get(4 * fat_slots, &f.fat_items)) || (rc = get(ray_slots, &f.slow_rays)) ||
+        (rc = get(3 * hit_slots, &f.hits[0])) || (rc = get(3 * hit_slots, &f.hits[1])))
+        return rc;
+    f.shadow_base = (uint32_t)ray_slots;
+    unsigned int* c = counters;
+    f.ray_counts[0] = c; c += f.n_seg;   f.ray_counts[1] = c; c += f.n_seg;
+    f.item_counts = c; c += f.n_seg;     f.fat_counts = c; c += f.n_seg;     f.slow_counts = c; c += f.n_seg;
+    f.hit_counts[0] = c; c += f.n_seg;   f.hit_counts[1] = c; c += f.n_seg;
+    f.chunk_counter = c; c += RT_MAX_DEPTH_LIMIT + 2;
+    f.slow_flags = c; c += RT_MAX_DEPTH_LIMIT + 2;
+    f.wave_stats = c;
+    if (aux && ((rc = get((size_t)n_pixels, &f.aux_flags)) || (rc = get((size_t)n_pixels, &f.aux_prim)) ||
+                (rc = get((size_t)n_pixels, &f.aux_inst))))
+        return rc;
     return RT_OK;
 }
 
-static uint32_t ceil_div(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+// The fields of a frame that do not depend on where its buffers live.
+static void fill_frame(const RtScene* s, const Geometry& g, uint32_t max_depth, DFrame* f) {
+    // [3][n_pixels] colour sums, then [n_pixels] poison words, in the one allocation that is cleared per frame
+    f->poison = reinterpret_cast<unsigned int*>(f->acc + (size_t)3 * g.n_pixels);
+    f->width = s->width; f->height = s->height;
+    f->tiles_x = g.tiles_x; f->tiles_y = g.tiles_y;
+    f->shard_index = g.shard_index; f->shard_count = g.shard_count;
+    f->n_local_tiles = g.tiles_per_shard; f->view_pixels = g.view_pixels; f->n_views = s->n_views; f->n_pixels = g.n_pixels;
+    f->max_depth = max_depth;
+    f->overflow = s->d_overflow;
+}
 
 static int ensure_frame(RtScene* s, const Geometry& g, uint32_t max_depth, bool aux) {
     const uint32_t blocks = s->list_blocks;
@@ -523,7 +592,7 @@ static int ensure_frame(RtScene* s, const Geometry& g, uint32_t max_depth, bool 
     if (const char* env = getenv("RT_QUEUE_CAPACITY")) { long v = atol(env); if (v > 0 && !s->debug_queue_capacity) capacity = (uint64_t)v; }
     capacity <<= s->capacity_shift;
     if (s->must_grow) {
-        // the last frame overflowed the lists it had - which may have been longer than this size asks for (see `fits`)
+        // a frame overflowed the lists it had - which may have been longer than this size asks for (see `fits`)
         while (!s->debug_queue_capacity && capacity <= s->key.capacity && capacity < (1ull << 30)) { capacity <<= 1; ++s->capacity_shift; }
         s->must_grow = false;
     }
@@ -543,68 +612,41 @@ static int ensure_frame(RtScene* s, const Geometry& g, uint32_t max_depth, bool 
         HIP_TRY(hipDeviceSynchronize());
         for (void* p : s->frame_allocs) (void)hipFree(p);
         s->frame_allocs.clear();
-        DFrame& f = s->f;
-        memset(&f, 0, sizeof(f));
-        f.n_seg = blocks + 1;
+        s->key = RtScene::FrameKey();
         // A block's own segment is never smaller than 1024 entries: with small frames the work is spread unevenly
         // over the blocks, and whatever does not fit a segment has to go through the shared overflow segment.
         const uint32_t seg_min = s->debug_queue_capacity ? 1u : 1024u;       // (tests force overflows with tiny lists)
-        auto seg = [&](uint64_t total) { return std::max<uint32_t>(ceil_div(total, blocks), seg_min); };
-        f.seg_rays = seg(capacity);          f.ovf_rays = (uint32_t)(capacity / 4 + 1024);
-        f.seg_items = seg(capacity);         f.ovf_items = (uint32_t)(capacity / 4 + 1024);
-        f.seg_fat = seg(capacity / 2);       f.ovf_fat = (uint32_t)(capacity / 8 + 1024);
-        f.seg_hits = seg(capacity / 2);      f.ovf_hits = (uint32_t)(capacity / 8 + 1024);
-        const size_t ray_slots = (size_t)blocks * f.seg_rays + f.ovf_rays;
-        const size_t item_slots = (size_t)blocks * f.seg_items + f.ovf_items;
-        const size_t fat_slots = (size_t)blocks * f.seg_fat + f.ovf_fat;
-        const size_t hit_slots = (size_t)blocks * f.seg_hits + f.ovf_hits;
-        const size_t all_ray_slots = ray_slots + hit_slots * s->d.n_lights;      // + the shadow rays, see DFrame::rays
-        if (all_ray_slots >= RT_META_RAY_LIMIT) return fail(RT_ERR_OUT_OF_RANGE, "a frame needs more than 2^31 ray slots per depth");
-        s->stats_words = (size_t)blocks * 4 * 8;
-        int rc;
-        // colour sums and poison words in one allocation, all counters in another: two clears per frame
-        long long* pixels = nullptr;
-        unsigned int* counters = nullptr;
-        s->pixel_clear_bytes = (size_t)3 * g.n_pixels * sizeof(long long) + (size_t)g.n_pixels * sizeof(unsigned int);
-        s->counter_words = 7 * (size_t)f.n_seg + 2 * (RT_MAX_DEPTH_LIMIT + 2) + s->stats_words;
-        if ((rc = frame_alloc(s, s->pixel_clear_bytes / sizeof(long long) + 1, &pixels)) ||
-            (rc = frame_alloc(s, s->counter_words, &counters)) || (rc = frame_alloc(s, (size_t)3 * g.n_pixels, &f.acc_big)) ||
-            (rc = frame_alloc(s, 2 * all_ray_slots, &f.rays[0])) || (rc = frame_alloc(s, 2 * all_ray_slots, &f.rays[1])) ||
-            (rc = frame_alloc(s, all_ray_slots, &f.best)) ||
-            (rc = frame_alloc(s, item_slots, &f.items)) || (rc = frame_alloc(s, item_slots, &f.item_results)) ||
-            (rc = frame_alloc(s, 4 * fat_slots, &f.fat_items)) || (rc = frame_alloc(s, ray_slots, &f.slow_rays)) ||
-            (rc = frame_alloc(s, 3 * hit_slots, &f.hits[0])) || (rc = frame_alloc(s, 3 * hit_slots, &f.hits[1])))
-            return rc;
-        f.shadow_base = (uint32_t)ray_slots;
-        HIP_TRY(hipMemset(f.acc_big, 0, (size_t)3 * g.n_pixels * sizeof(double)));     // rt_resolve keeps it zero afterwards
-        f.acc = pixels;
-        unsigned int* c = counters;
-        f.ray_counts[0] = c; c += f.n_seg;   f.ray_counts[1] = c; c += f.n_seg;
-        f.item_counts = c; c += f.n_seg;     f.fat_counts = c; c += f.n_seg;     f.slow_counts = c; c += f.n_seg;
-        f.hit_counts[0] = c; c += f.n_seg;   f.hit_counts[1] = c; c += f.n_seg;
-        f.chunk_counter = c; c += RT_MAX_DEPTH_LIMIT + 2;
-        f.slow_flags = c; c += RT_MAX_DEPTH_LIMIT + 2;
-        f.wave_stats = c;
-        if (aux && ((rc = frame_alloc(s, g.n_pixels, &f.aux_flags)) || (rc = frame_alloc(s, g.n_pixels, &f.aux_prim)) ||
-                    (rc = frame_alloc(s, g.n_pixels, &f.aux_inst))))
-            return rc;
-        f.overflow = s->d_overflow;
+        FrameSizes sz;
+        auto take = [&](size_t bytes, void** p) {
+            HIP_TRY(hipMalloc(p, bytes));
+            s->frame_allocs.push_back(*p);
+            return (int)RT_OK;
+        };
+        int rc = carve_frame(g.n_pixels, s->d.n_lights, blocks, capacity, seg_min, aux, take, &s->f, &sz);
+        if (rc) return rc;
+        s->stats_words = sz.stats_words;
+        s->counter_words = sz.counter_words;
+        HIP_TRY(hipMemset(s->f.acc_big, 0, (size_t)3 * g.n_pixels * sizeof(double)));     // rt_resolve keeps it zero afterwards
         s->key = k;
     }
-    DFrame& f = s->f;
-    // [3][n_pixels] colour sums, then [n_pixels] poison words, in the one allocation that is cleared per frame
-    f.poison = reinterpret_cast<unsigned int*>(f.acc + (size_t)3 * g.n_pixels);
+    fill_frame(s, g, max_depth, &s->f);
     s->pixel_clear_bytes = (size_t)3 * g.n_pixels * sizeof(long long) + (size_t)g.n_pixels * sizeof(unsigned int);
-    f.width = s->width; f.height = s->height;
-    f.tiles_x = g.tiles_x; f.tiles_y = g.tiles_y;
-    f.shard_index = g.shard_index; f.shard_count = g.shard_count;
-    f.n_local_tiles = g.tiles_per_shard; f.view_pixels = g.view_pixels; f.n_views = s->n_views; f.n_pixels = g.n_pixels;
-    f.max_depth = max_depth;
     return RT_OK;
 }
 
-// Enqueues one frame on `stream`: clear, primary rays, four launches per recursion depth (one more depth
-// than max_depth: the shadow rays of the deepest hits), resolve into d_out.
+// The host sees a frame's overflow through the word the kernels store sequence numbers to.
+static void note_overflow(RtScene* s) {
+    const uint32_t o = *s->h_overflow;
+    if (o != s->overflow_seen) {
+        s->overflow_seen = o;
+        s->overflow_unreported = true;
+        ++s->capacity_shift;               // the handle's own lists get longer at the next frame
+        s->must_grow = true;
+    }
+}
+
+// Enqueues one frame on `stream`: clear, primary rays, the launches of every recursion depth (one more depth than
+// max_depth: the shadow rays of the deepest hits), resolve into d_out.
 static int enqueue_frame(RtScene* s, const RtRenderParams* p, bool sharded, bool aux, uint8_t* d_out) {
     HIP_TRY(hipSetDevice(s->device));
     Geometry g;
@@ -614,20 +656,27 @@ static int enqueue_frame(RtScene* s, const RtRenderParams* p, bool sharded, bool
     if (max_depth > RT_MAX_DEPTH_LIMIT) return fail(RT_ERR_INVALID_ARGUMENT, "max_depth %u exceeds the limit of %d", max_depth, RT_MAX_DEPTH_LIMIT);
     if (s->d.n_lights > 255) return fail(RT_ERR_INVALID_ARGUMENT, "%u lights; at most 255 are supported", s->d.n_lights);
     if (p->mode > RT_MODE_DEPTH_MAP || p->reserved != 0) return fail(RT_ERR_INVALID_ARGUMENT, "unknown mode %u / reserved %u", p->mode, p->reserved);
-    // a list of an earlier frame did not fit: that frame was invalid, this one gets longer lists
-    if (*s->h_overflow) { *s->h_overflow = 0; ++s->capacity_shift; s->must_grow = true; }
-    if ((rc = ensure_frame(s, g, max_depth, aux))) return rc;
+    note_overflow(s);                      // a list of an earlier frame did not fit: that frame was invalid, this one gets longer lists
+    DFrame f;
+    FrameSizes sz;
+    uint32_t blocks = s->list_blocks;
+    {
+        if ((rc = ensure_frame(s, g, max_depth, aux))) return rc;
+        f = s->f;
+        sz.pixel_clear_bytes = s->pixel_clear_bytes; sz.counter_words = s->counter_words; sz.stats_words = s->stats_words;
+    }
     hipStream_t stream = p->stream ? (hipStream_t)p->stream : s->own_stream;
     s->last_stream = stream;
-    DFrame f = s->f;
     f.mode = p->mode;
+    if (++s->frame_seq == 0) s->frame_seq = 1;
+    f.overflow_seq = s->frame_seq;
     if (!aux) f.aux_flags = f.aux_prim = f.aux_inst = nullptr;
     HIP_TRY(hipEventRecord(s->ev_start, stream));
-    HIP_TRY(hipMemsetAsync(f.acc, 0, s->pixel_clear_bytes, stream));                              // colour sums + poison words
-    HIP_TRY(hipMemsetAsync(f.ray_counts[0], 0, s->counter_words * sizeof(unsigned int), stream));  // every counter + statistics
+    HIP_TRY(hipMemsetAsync(f.acc, 0, sz.pixel_clear_bytes, stream));                              // colour sums + poison words
+    HIP_TRY(hipMemsetAsync(f.ray_counts[0], 0, sz.counter_words * sizeof(unsigned int), stream));  // every counter + statistics
     if (aux) HIP_TRY(hipMemsetAsync(f.aux_flags, 0, (size_t)g.n_pixels * sizeof(unsigned int), stream));
     HIP_TRY(hipEventRecord(s->ev_trace_start, stream));
-    HIP_TRY(rt_launch_generate(&f, &s->views, s->list_blocks, stream));
+    HIP_TRY(rt_launch_generate(&f, &s->views, blocks, stream));
     // a depth map only looks at the primary hits
     const uint32_t last = p->mode == RT_MODE_DEPTH_MAP ? 0 : (s->d.n_lights > 0 ? max_depth : max_depth - 1);
     s->marked_levels = 0;
@@ -640,12 +689,14 @@ static int enqueue_frame(RtScene* s, const RtRenderParams* p, bool sharded, bool
         s->marked_levels = last + 1;
     }
     for (uint32_t level = 0; level <= last; ++level)
-        HIP_TRY(rt_launch_level(&s->d, &f, level, s->list_blocks, s->traverse_blocks, stream,
-                                s->kernel_timing ? &s->marks[(RT_N_LEVEL_KERNELS + 1) * (size_t)level] : nullptr));
+        HIP_TRY(rt_launch_level(&s->d, &f, level, blocks, s->traverse_blocks, stream,
+                                s->marked_levels ? &s->marks[(RT_N_LEVEL_KERNELS + 1) * (size_t)level] : nullptr));
     HIP_TRY(hipEventRecord(s->ev_trace_stop, stream));
     HIP_TRY(rt_launch_resolve(&f, d_out, bytes_per_pixel(p->output_format), g.shard_count > 1 ? 1u : 0u, stream));
     HIP_TRY(hipEventRecord(s->ev_stop, stream));
     s->timed = true;
+    s->last_f = f;
+    s->last_stats_words = sz.stats_words;
     return RT_OK;
 }
 
@@ -678,6 +729,8 @@ extern "C" int rt_render(RtScene* s, const RtRenderParams* p, uint8_t* out_pixel
     }
     bool want_aux = aux && (aux->prim_id || aux->instance_id || aux->flags);
     s->regrown = 0;
+    note_overflow(s);
+    const bool owed = s->overflow_unreported;      // an overflow of an earlier rt_render_device frame, still to be reported
     for (;;) {
         int rc = enqueue_frame(s, p, false, want_aux, s->d_pixels);
         if (rc) return rc;
@@ -693,7 +746,7 @@ extern "C" int rt_render(RtScene* s, const RtRenderParams* p, uint8_t* out_pixel
                 HIP_TRY(hipMalloc((void**)&s->d_aux_flags_out, n));
                 s->aux_out_pixels = n;
             }
-            DFrame f = s->f;
+            DFrame f = s->last_f;
             HIP_TRY(rt_launch_resolve_aux(&f, s->d_aux_prim_out, s->d_aux_inst_out, s->d_aux_flags_out, stream));
             if (aux->prim_id) HIP_TRY(hipMemcpyAsync(aux->prim_id, s->d_aux_prim_out, n * 4, hipMemcpyDeviceToHost, stream));
             if (aux->instance_id) HIP_TRY(hipMemcpyAsync(aux->instance_id, s->d_aux_inst_out, n * 4, hipMemcpyDeviceToHost, stream));
@@ -701,8 +754,12 @@ extern "C" int rt_render(RtScene* s, const RtRenderParams* p, uint8_t* out_pixel
         }
         HIP_TRY(hipMemcpyAsync(out_pixels, s->d_pixels, bytes, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        if (!*s->h_overflow) break;
-        // a ray list did not fit: enlarge (enqueue_frame sees the flag) and render the frame again
+        const uint32_t seen = s->overflow_seen;
+        note_overflow(s);
+        if (s->overflow_seen == seen) break;
+        // a ray list did not fit: the lists get longer (note_overflow) and the frame is rendered again, which is all
+        // the report this overflow needs
+        s->overflow_unreported = owed;
         ++s->regrown;
         if (s->regrown > 16) return fail(RT_ERR_OUT_OF_RANGE, "the ray lists keep overflowing");
     }
@@ -732,9 +789,9 @@ extern "C" int rt_assemble_shards(RtScene* s, const RtRenderParams* p, const voi
 }
 
 static int sum_wave_stats(RtScene* s, uint64_t sums[8]) {
-    size_t n = s->stats_words;
+    size_t n = s->last_stats_words;
     std::vector<unsigned int> host(n);
-    HIP_TRY(hipMemcpy(host.data(), s->f.wave_stats, n * sizeof(unsigned int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(host.data(), s->last_f.wave_stats, n * sizeof(unsigned int), hipMemcpyDeviceToHost));
     for (int k = 0; k < 8; ++k) sums[k] = 0;
     for (size_t i = 0; i < n; ++i) sums[i % 8] += host[i];
     return RT_OK;
@@ -745,8 +802,12 @@ extern "C" int rt_last_ray_counts(RtScene* s, uint64_t counters[RT_N_COUNTERS]) 
     if (!s->timed) return fail(RT_ERR_INVALID_ARGUMENT, "nothing has been rendered on this handle yet");
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipStreamSynchronize(s->last_stream));
-    if (*s->h_overflow)
-        return fail(RT_ERR_OUT_OF_RANGE, "a ray list overflowed during the last frame: its output is incomplete; the next frame gets longer lists");
+    note_overflow(s);
+    if (s->overflow_unreported) {
+        s->overflow_unreported = false;
+        return fail(RT_ERR_OUT_OF_RANGE, "a ray list overflowed in a frame rendered since the last query (the latest such frame is number %u of "
+                    "this handle, %u have been enqueued): its output is incomplete; the next frame gets longer lists", s->overflow_seen, s->frame_seq);
+    }
     uint64_t sums[8];
     int rc = sum_wave_stats(s, sums);
     if (rc) return rc;

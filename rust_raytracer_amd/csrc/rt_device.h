@@ -162,5 +162,9 @@ struct DFrame {
     float4* hits[2];                 // Phong-shaded hits waiting for their shadow rays, 3 float4 each
     unsigned int* hit_counts[2];     // [n_seg]
     unsigned int* wave_stats;        // [waves][8]: rays, primary, shadow, reflected, transmitted
-    unsigned int* overflow;          // set to 1 when a list did not fit (the frame is then invalid)
+    // A list did not fit (the frame is then invalid): the kernels store the frame's sequence number here.  The host
+    // only ever reads the word, so no report can be lost to a clear; frames of one handle run one after the other,
+    // so the word names the latest frame that overflowed.
+    unsigned int* overflow;
+    uint32_t overflow_seq;           // this frame's sequence number on its handle, never 0
 };

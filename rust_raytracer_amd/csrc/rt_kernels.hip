@@ -494,7 +494,7 @@ __device__ __forceinline__ uint32_t locate_chunk(const uint32_t* pre, uint32_t n
 // even the overflow segment is full).  Must be called by all lanes of the wave.
 __device__ __forceinline__ uint32_t append_slot(bool want, uint32_t* lds_counter, uint32_t seg_cap, uint32_t n_seg,
                                                 unsigned int* counts, uint32_t ovf_cap, unsigned int* overflow_flag,
-                                                uint32_t lane) {
+                                                uint32_t overflow_seq, uint32_t lane) {
     unsigned long long mask = __ballot(want);
     if (!mask) return RT_REF_NONE;
     uint32_t leader = __ffsll((long long)mask) - 1;
@@ -506,7 +506,7 @@ __device__ __forceinline__ uint32_t append_slot(bool want, uint32_t* lds_counter
     if (k < seg_cap) return blockIdx.x * seg_cap + k;
     uint32_t j = atomicAdd(&counts[n_seg - 1], 1u);
     if (j < ovf_cap) return (n_seg - 1) * seg_cap + j;
-    *overflow_flag = 1u;
+    *overflow_flag = overflow_seq;
     return RT_REF_NONE;
 }
 
@@ -641,7 +641,7 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_generate(const DFrame F, 
         if (inside) rr.ray = primary_ray(F, V.m[wave_view < F.n_views ? wave_view : 0], col, row);
         rr.throughput = 1.0f;
         rr.meta = p;
-        uint32_t slot = append_slot(inside, &out_n, F.seg_rays, F.n_seg, F.ray_counts[0], F.ovf_rays, F.overflow, lane);
+        uint32_t slot = append_slot(inside, &out_n, F.seg_rays, F.n_seg, F.ray_counts[0], F.ovf_rays, F.overflow, F.overflow_seq, lane);
         if (slot != RT_REF_NONE) store_rec(F.rays[0], slot, rr);
     }
     __syncthreads();
@@ -752,7 +752,7 @@ __global__ void __launch_bounds__(RT_SETUP_THREADS) rt_setup(const DScene S, con
         const bool easy = finite3(r.o) && finite3(r.d) && fabsf(r.d.x) + fabsf(r.d.y) + fabsf(r.d.z) < 4.0f &&
                           S.all_cullable != 0 && o_l1 < 1e15f;
         {
-            const uint32_t slot = append_slot(active && !easy, &slow_n, F.seg_rays, F.n_seg, F.slow_counts, F.ovf_rays, F.overflow, lane);
+            const uint32_t slot = append_slot(active && !easy, &slow_n, F.seg_rays, F.n_seg, F.slow_counts, F.ovf_rays, F.overflow, F.overflow_seq, lane);
             if (slot != RT_REF_NONE) F.slow_rays[slot] = gi;
         }
         active = active && easy;
@@ -796,7 +796,7 @@ __global__ void __launch_bounds__(RT_SETUP_THREADS) rt_setup(const DScene S, con
                     else {
                         const uint32_t j = atomicAdd(&F.item_counts[F.n_seg - 1], 1u);      // the shared overflow segment
                         if (j < F.ovf_items) slot = (F.n_seg - 1) * F.seg_items + j;
-                        else *F.overflow = 1u;
+                        else *F.overflow = F.overflow_seq;
                     }
                     if (slot != RT_REF_NONE) F.items[slot] = make_uint2(gi, left & 0x7FFFFFFFu);
                 } else {
@@ -841,7 +841,7 @@ __global__ void __launch_bounds__(RT_SETUP_THREADS) rt_setup(const DScene S, con
                     else {
                         const uint32_t j = atomicAdd(&F.item_counts[F.n_seg - 1], 1u);      // the shared overflow segment
                         if (j < F.ovf_items) slot = (F.n_seg - 1) * F.seg_items + j;
-                        else *F.overflow = 1u;
+                        else *F.overflow = F.overflow_seq;
                     }
                     if (slot != RT_REF_NONE) F.items[slot] = make_uint2(gi, g0 + k);
                 }
@@ -986,12 +986,12 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_setup_slow(const DScene S
                     want_item = pass;
                 }
             }
-            uint32_t slot = append_slot(want_item, &out_n, F.seg_items, F.n_seg, F.item_counts, F.ovf_items, F.overflow, lane);
+            uint32_t slot = append_slot(want_item, &out_n, F.seg_items, F.n_seg, F.item_counts, F.ovf_items, F.overflow, F.overflow_seq, lane);
             if (slot != RT_REF_NONE) F.items[slot] = make_uint2(gi, ii);
         }
         // a mesh winner found on the exact path is recorded as a finished work item
         {
-            uint32_t slot = append_slot(active && exact_mesh, &out_n, F.seg_items, F.n_seg, F.item_counts, F.ovf_items, F.overflow, lane);
+            uint32_t slot = append_slot(active && exact_mesh, &out_n, F.seg_items, F.n_seg, F.item_counts, F.ovf_items, F.overflow, F.overflow_seq, lane);
             if (slot != RT_REF_NONE) {
                 F.items[slot] = make_uint2(gi, ex_inst | RT_ITEM_DONE);
                 F.item_results[slot] = make_float4(ex_t, ex_u, ex_v, __uint_as_float(ex_slot));
@@ -1072,7 +1072,7 @@ __global__ void __launch_bounds__(RT_ROOT_THREADS) rt_root(const DScene S, const
                 q3 = make_float4(__uint_as_float(gi), __uint_as_float(ii | (fast ? RT_FAT_FAST : 0u)), __uint_as_float(item), 0.0f);
             }
         }
-        const uint32_t slot = append_slot(pass, &out_n, F.seg_fat, F.n_seg, F.fat_counts, F.ovf_fat, F.overflow, lane);
+        const uint32_t slot = append_slot(pass, &out_n, F.seg_fat, F.n_seg, F.fat_counts, F.ovf_fat, F.overflow, F.overflow_seq, lane);
         if (slot != RT_REF_NONE) {
             F.fat_items[4 * (size_t)slot] = q0; F.fat_items[4 * (size_t)slot + 1] = q1;
             F.fat_items[4 * (size_t)slot + 2] = q2; F.fat_items[4 * (size_t)slot + 3] = q3;
@@ -1584,7 +1584,7 @@ __global__ void __launch_bounds__(RT_SHADE_THREADS) rt_shade(const DScene S, con
         }
 
         // ---- append: hit record, its shadow rays (one per light, raytracer.rs:77-79), child rays ----------
-        const uint32_t hit_slot = append_slot(emit_hit, &out_hits, F.seg_hits, F.n_seg, F.hit_counts[p], F.ovf_hits, F.overflow, lane);
+        const uint32_t hit_slot = append_slot(emit_hit, &out_hits, F.seg_hits, F.n_seg, F.hit_counts[p], F.ovf_hits, F.overflow, F.overflow_seq, lane);
         if (hit_slot != RT_REF_NONE) {
             float4* H = F.hits[p] + 3 * (size_t)hit_slot;
             H[0] = make_float4(hit.position.x, hit.position.y, hit.position.z, __uint_as_float(hit.material));
@@ -1606,11 +1606,11 @@ __global__ void __launch_bounds__(RT_SHADE_THREADS) rt_shade(const DScene S, con
             }
         }
         {
-            const uint32_t slot = append_slot(emit_r, &out_rays, F.seg_rays, F.n_seg, F.ray_counts[q], F.ovf_rays, F.overflow, lane);
+            const uint32_t slot = append_slot(emit_r, &out_rays, F.seg_rays, F.n_seg, F.ray_counts[q], F.ovf_rays, F.overflow, F.overflow_seq, lane);
             if (slot != RT_REF_NONE) store_rec(rays_out, slot, rec_r);
         }
         {
-            const uint32_t slot = append_slot(emit_t, &out_rays, F.seg_rays, F.n_seg, F.ray_counts[q], F.ovf_rays, F.overflow, lane);
+            const uint32_t slot = append_slot(emit_t, &out_rays, F.seg_rays, F.n_seg, F.ray_counts[q], F.ovf_rays, F.overflow, F.overflow_seq, lane);
             if (slot != RT_REF_NONE) store_rec(rays_out, slot, rec_t);
         }
     }

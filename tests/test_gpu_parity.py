@@ -156,6 +156,43 @@ def test_queue_overflow_is_harmless(scenes_dir, model_dir):
     assert_parity(got, want)
 
 
+def test_overflow_of_a_device_frame_is_reported_once(scenes_dir, model_dir):
+    """rt_render_device cannot redo a frame whose ray lists overflowed: rt_last_ray_counts must say so even when further
+    frames were enqueued in between (the report is sticky), say it once, and the lists grow until a frame fits."""
+    import torch
+    s = load(scenes_dir, model_dir, "cornell_box", 320, 180)
+    m, w, h = s.camera()
+    dev = native.DeviceScene(s.desc(), 0)
+    try:
+        dev.set_camera(m, w, h)
+        want = dev.render()["rgb"]
+        dev.debug_set_queue_capacity(1000)
+        side = torch.cuda.Stream()
+        torch.cuda.set_stream(side)
+        out = torch.zeros(h * w * 3, dtype=torch.uint8, device="cuda")
+        dev.render_device(out.data_ptr(), stream=side.cuda_stream)      # far too short lists
+        torch.cuda.synchronize()
+        dev.render_device(out.data_ptr(), stream=side.cuda_stream)      # a later frame must not erase the report
+        dev.render_device(out.data_ptr(), stream=side.cuda_stream)
+        with pytest.raises(native.RtError) as e:
+            dev.last_ray_counts()
+        assert e.value.code == abi.RT_ERR_OUT_OF_RANGE
+        for _ in range(20):                                              # the lists double after every overflow seen
+            dev.render_device(out.data_ptr(), stream=side.cuda_stream)
+            try:
+                counts = dev.last_ray_counts()
+                break
+            except native.RtError:
+                continue
+        else:
+            raise AssertionError("the lists never grew enough")
+        assert counts[0] > w * h
+        assert dev.last_ray_counts().tolist() == counts.tolist()        # reported once: asking again is fine
+        assert np.array_equal(out.cpu().numpy().reshape(h, w, 3), want)
+    finally:
+        dev.close()
+
+
 def test_no_lights_and_empty_scene(scenes_dir, model_dir):
     scene = json.load(open(os.path.join(scenes_dir, "cornell_box.json")))
     scene["lights"] = []
