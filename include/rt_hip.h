@@ -251,6 +251,24 @@ int rt_render(RtScene* scene, const RtRenderParams* params, uint8_t* out_pixels,
  * tile; pixels outside the frame are zero.  Use rt_shard_bytes for the buffer size. */
 int rt_render_device(RtScene* scene, const RtRenderParams* params, void* d_out);
 
+/* rt_render_device without any allocation.  No counterpart in the reference: it exists for callers that cannot
+ * allocate device memory at the time they render - code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc.  Same arguments, same output bytes as rt_render_device, but the frame's work buffers (ray lists,
+ * candidate keys, BVH work items, hit records, colour sums, counters) are carved out of one static array in device
+ * memory that the library holds on every GPU it runs on (rt_noalloc_scratch_bytes: 128 MiB) instead of the handle's
+ * own buffers, and the call performs no hipMalloc / hipFree, whatever the frame size or the handle's history.
+ * Limits: the frame's buffers must fit the array - about 2.6 KB per local pixel (views x this shard's tiles) in a scene
+ * with two lights, i.e. frames up to roughly 256x192; larger ones fail with RT_ERR_OUT_OF_RANGE and a message that
+ * names both sizes (use rt_render_device for them).  The lists hold eight rays per pixel and recursion depth and
+ * cannot grow: if a frame needs more, rt_last_ray_counts reports the overflow as it does after rt_render_device.
+ * Kernel timing mode is ignored.  All calls on one GPU - from any handle, on any stream - share the one array:
+ * calls that overlap in time race and corrupt each other's frames, so issue them on one stream or order them
+ * with events.  rt_last_ray_counts / rt_last_render_ms refer to such a frame like to any other. */
+int rt_render_device_noalloc(RtScene* scene, const RtRenderParams* params, void* d_out);
+
+/* Size of that static array in bytes. */
+int rt_noalloc_scratch_bytes(uint64_t* out_bytes);
+
 /* Bytes one shard writes in rt_render_device per view (equal for every shard_index: the tile count is
  * rounded up to a multiple of shard_count so that gathers are uniform). */
 int rt_shard_bytes(const RtScene* scene, const RtRenderParams* params, uint64_t* out_bytes);

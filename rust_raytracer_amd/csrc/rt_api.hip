@@ -44,6 +44,8 @@ static int fail(int code, const char* fmt, ...) {
         if (e_ != hipSuccess) return fail(RT_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
+static int scratch_for_device(int device, void** out);
+
 // instance counts above this get a range tree over the culling boxes (rt_setup walks it instead of scanning)
 #define RT_RANGE_TREE_MIN 16
 
@@ -65,6 +67,7 @@ struct RtScene {
     bool overflow_unreported = false;
     uint32_t capacity_shift = 0;        // lists are (default capacity << capacity_shift) rays long
     bool must_grow = false;             // a frame overflowed: the next one needs lists longer than it had
+    void* scratch = nullptr;            // this device's copy of the static scratch array (rt_render_device_noalloc)
     uint32_t regrown = 0;               // times rt_render had to enlarge the lists for its last frame
     std::vector<void*> scene_allocs;
     DScene d{};
@@ -447,6 +450,7 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device_id, RtScene**
         hipHostGetDevicePointer((void**)&s->d_overflow, const_cast<unsigned int*>(s->h_overflow), 0) != hipSuccess)
         return bail(fail(RT_ERR_DEVICE, "cannot allocate the host-visible overflow flag"));
     *s->h_overflow = 0;
+    if ((rc = scratch_for_device(device_id, &s->scratch))) return bail(rc);
     *out_scene = s;
     return RT_OK;
 }
@@ -521,7 +525,8 @@ struct FrameSizes { size_t pixel_clear_bytes = 0, counter_words = 0, stats_words
 
 // Lays out the per-frame buffers of DFrame for `n_pixels` local pixels, lists of `capacity` rays per recursion depth cut
 // into `blocks` producer segments (none shorter than seg_min) plus the shared overflow segment.  Memory comes from
-// `take(bytes, &ptr)`, which returns RT_OK or an error code: hipMalloc for the handle's own buffers.
+// `take(bytes, &ptr)`, which returns RT_OK or an error code: hipMalloc for the handle's own buffers, a bump pointer over
+// the static scratch array for rt_render_device_noalloc.
 template <class Take>
 static int carve_frame(uint32_t n_pixels, uint32_t n_lights, uint32_t blocks, uint64_t capacity, uint32_t seg_min, bool aux,
                        Take&& take, DFrame* out, FrameSizes* sz) {
@@ -634,6 +639,29 @@ static int ensure_frame(RtScene* s, const Geometry& g, uint32_t max_depth, bool 
     return RT_OK;
 }
 
+// ---- the static scratch of rt_render_device_noalloc -------------------------------------------------------------
+// One array per GPU the library is loaded on, held until the process ends.  Host code never uses the array's name
+// as an address: rt_scene_create asks the runtime for this device's copy once (scratch_for_device) and everything
+// else goes through that pointer.
+#define RT_NOALLOC_SCRATCH_BYTES (128ull << 20)
+#define RT_NOALLOC_MAX_DEVICES 64
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES];
+
+static int scratch_for_device(int device, void** out) {
+    static std::mutex lock;
+    static void* table[RT_NOALLOC_MAX_DEVICES] = {};
+    *out = nullptr;
+    if (device < 0 || device >= RT_NOALLOC_MAX_DEVICES) return RT_OK;      // such a handle only lacks the entry point below
+    std::lock_guard<std::mutex> hold(lock);
+    if (!table[device]) {
+        void* p = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));              // the device of the handle is current here
+        table[device] = p;
+    }
+    *out = table[device];
+    return RT_OK;
+}
+
 // The host sees a frame's overflow through the word the kernels store sequence numbers to.
 static void note_overflow(RtScene* s) {
     const uint32_t o = *s->h_overflow;
@@ -646,8 +674,9 @@ static void note_overflow(RtScene* s) {
 }
 
 // Enqueues one frame on `stream`: clear, primary rays, the launches of every recursion depth (one more depth than
-// max_depth: the shadow rays of the deepest hits), resolve into d_out.
-static int enqueue_frame(RtScene* s, const RtRenderParams* p, bool sharded, bool aux, uint8_t* d_out) {
+// max_depth: the shadow rays of the deepest hits), resolve into d_out.  `noalloc`: the frame's buffers are carved
+// out of the static scratch instead of the handle's own allocations, and nothing here allocates.
+static int enqueue_frame(RtScene* s, const RtRenderParams* p, bool sharded, bool aux, uint8_t* d_out, bool noalloc = false) {
     HIP_TRY(hipSetDevice(s->device));
     Geometry g;
     int rc = frame_geometry(s, p, sharded, &g);
@@ -660,7 +689,26 @@ static int enqueue_frame(RtScene* s, const RtRenderParams* p, bool sharded, bool
     DFrame f;
     FrameSizes sz;
     uint32_t blocks = s->list_blocks;
-    {
+    if (noalloc) {
+        if (!s->scratch) return fail(RT_ERR_DEVICE, "rt_render_device_noalloc: device %d has no scratch array", s->device);
+        // one list segment per compute unit, eight rays per pixel and depth, as the handle's own lists start out
+        blocks = (uint32_t)s->n_cus;
+        size_t used = 0;
+        auto take = [&](size_t bytes, void** ptr) {
+            const size_t at = (used + 255) & ~(size_t)255;
+            *ptr = static_cast<unsigned char*>(s->scratch) + at;           // never dereferenced beyond the limit checked below
+            used = at + bytes;
+            return (int)RT_OK;
+        };
+        const uint64_t capacity = std::max<uint64_t>((uint64_t)8 * g.n_pixels, 4096);
+        if ((rc = carve_frame(g.n_pixels, s->d.n_lights, blocks, capacity, 64u, false, take, &f, &sz))) return rc;
+        if (used > RT_NOALLOC_SCRATCH_BYTES)
+            return fail(RT_ERR_OUT_OF_RANGE,
+                        "rt_render_device_noalloc: %u pixels with %u lights need %llu bytes of scratch, the static array holds %llu; "
+                        "use rt_render_device for frames of this size", g.n_pixels, s->d.n_lights, (unsigned long long)used,
+                        (unsigned long long)RT_NOALLOC_SCRATCH_BYTES);
+        fill_frame(s, g, max_depth, &f);
+    } else {
         if ((rc = ensure_frame(s, g, max_depth, aux))) return rc;
         f = s->f;
         sz.pixel_clear_bytes = s->pixel_clear_bytes; sz.counter_words = s->counter_words; sz.stats_words = s->stats_words;
@@ -674,13 +722,15 @@ static int enqueue_frame(RtScene* s, const RtRenderParams* p, bool sharded, bool
     HIP_TRY(hipEventRecord(s->ev_start, stream));
     HIP_TRY(hipMemsetAsync(f.acc, 0, sz.pixel_clear_bytes, stream));                              // colour sums + poison words
     HIP_TRY(hipMemsetAsync(f.ray_counts[0], 0, sz.counter_words * sizeof(unsigned int), stream));  // every counter + statistics
+    // the scratch array keeps what the last call on this GPU left in it
+    if (noalloc) HIP_TRY(hipMemsetAsync(f.acc_big, 0, (size_t)3 * g.n_pixels * sizeof(double), stream));
     if (aux) HIP_TRY(hipMemsetAsync(f.aux_flags, 0, (size_t)g.n_pixels * sizeof(unsigned int), stream));
     HIP_TRY(hipEventRecord(s->ev_trace_start, stream));
     HIP_TRY(rt_launch_generate(&f, &s->views, blocks, stream));
     // a depth map only looks at the primary hits
     const uint32_t last = p->mode == RT_MODE_DEPTH_MAP ? 0 : (s->d.n_lights > 0 ? max_depth : max_depth - 1);
     s->marked_levels = 0;
-    if (s->kernel_timing) {
+    if (s->kernel_timing && !noalloc) {
         while (s->marks.size() < (RT_N_LEVEL_KERNELS + 1) * (size_t)(last + 1)) {
             hipEvent_t e = nullptr;
             HIP_TRY(hipEventCreate(&e));
@@ -713,6 +763,17 @@ extern "C" int rt_shard_bytes(const RtScene* s, const RtRenderParams* p, uint64_
 extern "C" int rt_render_device(RtScene* s, const RtRenderParams* p, void* d_out) {
     if (!s || !p || !d_out) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_device: null argument");
     return enqueue_frame(s, p, true, false, static_cast<uint8_t*>(d_out));
+}
+
+extern "C" int rt_render_device_noalloc(RtScene* s, const RtRenderParams* p, void* d_out) {
+    if (!s || !p || !d_out) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_device_noalloc: null argument");
+    return enqueue_frame(s, p, true, false, static_cast<uint8_t*>(d_out), true);
+}
+
+extern "C" int rt_noalloc_scratch_bytes(uint64_t* out_bytes) {
+    if (!out_bytes) return fail(RT_ERR_INVALID_ARGUMENT, "rt_noalloc_scratch_bytes: null argument");
+    *out_bytes = RT_NOALLOC_SCRATCH_BYTES;
+    return RT_OK;
 }
 
 extern "C" int rt_render(RtScene* s, const RtRenderParams* p, uint8_t* out_pixels, RtAux* aux) {

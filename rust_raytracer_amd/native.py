@@ -13,7 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librt_hip.so")
 
 # every function include/rt_hip.h declares
-EXPORTS = ["rt_scene_create", "rt_scene_set_camera", "rt_scene_set_views", "rt_render", "rt_render_device", "rt_shard_bytes",
+EXPORTS = ["rt_scene_create", "rt_scene_set_camera", "rt_scene_set_views", "rt_render", "rt_render_device", "rt_render_device_noalloc",
+           "rt_noalloc_scratch_bytes", "rt_shard_bytes",
            "rt_assemble_shards", "rt_last_ray_counts", "rt_last_render_ms", "rt_last_trace_ms", "rt_set_kernel_timing",
            "rt_last_kernel_ms", "rt_scene_destroy",
            "rt_debug_set_queue_capacity", "rt_debug_last_regrown", "rt_last_error"]
@@ -69,6 +70,8 @@ def lib():
         L.rt_scene_set_views.argtypes = [vp, C.POINTER(C.c_float), u32, u32, u32]
         L.rt_render.argtypes = [vp, C.POINTER(abi.RtRenderParams), vp, C.POINTER(abi.RtAux)]
         L.rt_render_device.argtypes = [vp, C.POINTER(abi.RtRenderParams), vp]
+        L.rt_render_device_noalloc.argtypes = [vp, C.POINTER(abi.RtRenderParams), vp]
+        L.rt_noalloc_scratch_bytes.argtypes = [C.POINTER(C.c_uint64)]
         L.rt_shard_bytes.argtypes = [vp, C.POINTER(abi.RtRenderParams), C.POINTER(C.c_uint64)]
         L.rt_assemble_shards.argtypes = [vp, C.POINTER(abi.RtRenderParams), vp, vp]
         L.rt_last_ray_counts.argtypes = [vp, C.POINTER(C.c_uint64)]
@@ -170,11 +173,13 @@ class DeviceScene:
         return int(n.value)
 
     def render_device(self, d_out: int, max_depth: int = 10, channels: int = 3, shard_index: int = 0,
-                      shard_count: int = 1, stream: int | None = None):
-        """Asynchronous render into device memory at address `d_out` (see rt_render_device)."""
+                      shard_count: int = 1, stream: int | None = None, noalloc: bool = False):
+        """Asynchronous render into device memory at address `d_out` (see rt_render_device); `noalloc` selects
+        rt_render_device_noalloc, whose work buffers live in the library's static scratch array."""
         p = self._params(max_depth, abi.RT_FORMAT_RGBA8 if channels == 4 else abi.RT_FORMAT_RGB8, shard_index,
                          shard_count, stream)
-        check(lib().rt_render_device(self._h, C.byref(p), C.c_void_p(d_out)))
+        fn = lib().rt_render_device_noalloc if noalloc else lib().rt_render_device
+        check(fn(self._h, C.byref(p), C.c_void_p(d_out)))
 
     def assemble_shards(self, d_gathered: int, d_frame: int, shard_count: int, channels: int = 3,
                         stream: int | None = None):

@@ -1,0 +1,62 @@
+"""rt_render_device_noalloc (work buffers in the library's static device scratch array, no allocation in the call)
+against rt_render_device on the same handle: byte-identical output and equal ray counts, on two calls in a row, the
+second with a smaller input; frames beyond the array are refused with a message.  Collected last (file name) so that a
+failure here cannot hide another test behind `pytest -x`."""
+import os
+
+import numpy as np
+import pytest
+
+from rust_raytracer_amd import native
+
+pytestmark = pytest.mark.gpu
+
+
+def test_noalloc_matches_render_device(scenes_dir, model_dir):
+    import ctypes as C
+    import torch
+    n = C.c_uint64()
+    native.check(native.lib().rt_noalloc_scratch_bytes(C.byref(n)))
+    assert n.value == 128 << 20
+    host = native.HostScene.load(os.path.join(scenes_dir, "reflective_bunnies.json"), model_dir)
+    dev = native.DeviceScene(host.desc(), 0)
+    other = native.DeviceScene(host.desc(), 0)             # a second handle: the scratch array belongs to the GPU, not to a handle
+    side = torch.cuda.Stream()
+    torch.cuda.set_stream(side)
+    stream = side.cuda_stream
+    try:
+        # two calls in a row, the second smaller (it finds the first one's leftovers in the array), then a sharded one
+        for handle, (w, h), (shard, shards) in ((dev, (256, 144), (0, 1)), (dev, (160, 90), (0, 1)), (other, (250, 190), (1, 3)),
+                                                (dev, (96, 64), (0, 1))):
+            host.resize_screen(w, h)
+            m, w, h = host.camera()
+            handle.set_camera(m, w, h)
+            nbytes = handle.shard_bytes(shards)
+            want = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+            got = torch.full((nbytes,), 7, dtype=torch.uint8, device="cuda")
+            handle.render_device(want.data_ptr(), shard_index=shard, shard_count=shards, stream=stream)
+            want_counts = handle.last_ray_counts()
+            handle.render_device(got.data_ptr(), shard_index=shard, shard_count=shards, stream=stream, noalloc=True)
+            got_counts = handle.last_ray_counts()             # also raises if a list of the scratch frame overflowed
+            torch.cuda.synchronize()
+            assert torch.equal(got, want), (w, h, shards)
+            assert got_counts.tolist() == want_counts.tolist() and got_counts[0] > w * h // shards
+            assert want.any()
+        # a frame whose buffers do not fit the array: refused, with both sizes in the message, nothing rendered
+        host.resize_screen(1920, 1080)
+        m, w, h = host.camera()
+        dev.set_camera(m, w, h)
+        big = torch.zeros(w * h * 3, dtype=torch.uint8, device="cuda")
+        with pytest.raises(native.RtError) as e:
+            dev.render_device(big.data_ptr(), stream=stream, noalloc=True)
+        assert e.value.code == native.abi.RT_ERR_OUT_OF_RANGE and "scratch" in str(e.value)
+        torch.cuda.synchronize()
+        assert not big.any()
+        dev.render_device(big.data_ptr(), stream=stream)        # the allocating entry point still takes it
+        dev.last_ray_counts()
+        assert big.any()
+    finally:
+        torch.cuda.synchronize()
+        dev.close()
+        other.close()
+        host.close()
