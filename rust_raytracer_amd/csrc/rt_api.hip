@@ -120,7 +120,9 @@ namespace {
 struct MeshLayout {
     uint32_t root_ref = RT_REF_NONE;
     float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};
-    uint32_t stack_need = 1;
+    uint32_t stack_need = 1;         // entries the reference's own walk can need (intersect.rs:240-256)
+    uint32_t root_ref4 = RT_REF_NONE;   // the same tree with every other level folded away (DScene::nodes4)
+    uint32_t stack_need4 = 1;        // entries a depth-first walk of that tree can need
     float max_edge_product = 0.0f;   // max |e1| * |e2| over the mesh's triangles
     float max_edge_sum = 0.0f;       // max |e1| + |e2|
 };
@@ -211,6 +213,70 @@ static int layout_mesh(const RtSceneDesc* desc, uint32_t mesh_index, std::vector
         }
     }
     out->stack_need = need;
+    return RT_OK;
+}
+
+// Folds every other level of a mesh's binary tree away: the 4-wide node of binary inner node N holds, for each of
+// N's two children, the child itself when it is a leaf and otherwise the child's own two children - two to four
+// entries, each with its box, in the order the reference's walk would reach them (right before left at both levels,
+// intersect.rs:253-256).  A ray passes the box of a folded-away child whenever it passes a box inside it (the slab test
+// of intersect.rs:185-226 is monotone in the box), so a walk of the 4-wide tree tests exactly the leaves the
+// reference's walk tests.  `nodes` is the binary layout of layout_mesh; leaves keep their slots.
+static int collapse_mesh(const std::vector<float4>& nodes, uint32_t mesh_index, MeshLayout* ml, std::vector<float4>& nodes4) {
+    ml->root_ref4 = ml->root_ref;
+    ml->stack_need4 = 1;
+    if (ml->root_ref == RT_REF_NONE || (ml->root_ref & RT_REF_LEAF_BIT)) return RT_OK;
+    auto word = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+    struct Entry { float lo[3], hi[3]; uint32_t ref; };
+    // the two children of binary node b, right first
+    auto children = [&](uint32_t b, Entry out[2]) {
+        const float4 &a = nodes[4 * (size_t)b], &c = nodes[4 * (size_t)b + 1], &d = nodes[4 * (size_t)b + 2], &e = nodes[4 * (size_t)b + 3];
+        Entry l = {{a.x, a.y, a.z}, {a.w, c.x, c.y}, word(e.x)}, r = {{c.z, c.w, d.x}, {d.y, d.z, d.w}, word(e.y)};
+        out[0] = r; out[1] = l;
+    };
+    struct Job { uint32_t binary; uint32_t slot4; uint32_t pending; uint32_t depth; };
+    std::vector<Job> jobs;
+    auto new_node = [&]() { const uint32_t k = (uint32_t)(nodes4.size() / 8); nodes4.resize(nodes4.size() + 8, f4(0, 0, 0, 0)); return k; };
+    ml->root_ref4 = new_node();
+    jobs.push_back({ml->root_ref, ml->root_ref4, 0, 0});
+    while (!jobs.empty()) {
+        const Job job = jobs.back();
+        jobs.pop_back();
+        if (job.depth > 2 * RT_BVH_STACK_LEN) return fail(RT_ERR_INVALID_ARGUMENT, "mesh %u: BVH is not a tree", mesh_index);
+        Entry two[2], entries[4];
+        uint32_t n = 0;
+        children(job.binary, two);
+        for (int side = 0; side < 2; ++side) {
+            if (two[side].ref == RT_REF_NONE) continue;
+            if (two[side].ref & RT_REF_LEAF_BIT) { entries[n++] = two[side]; continue; }
+            Entry grand[2];
+            children(two[side].ref, grand);
+            for (int g = 0; g < 2; ++g)
+                if (grand[g].ref != RT_REF_NONE) entries[n++] = grand[g];
+        }
+        // a walk that goes on with one entry keeps the others on its stack
+        const uint32_t pending = job.pending + (n ? n - 1 : 0);
+        if (pending + 1 > ml->stack_need4) ml->stack_need4 = pending + 1;
+        uint32_t refs[4] = {RT_REF_NONE, RT_REF_NONE, RT_REF_NONE, RT_REF_NONE};
+        float box[4][6];
+        for (uint32_t c = 0; c < 4; ++c)
+            for (int k = 0; k < 6; ++k) box[c][k] = 0.0f;
+        for (uint32_t c = 0; c < n; ++c) {
+            for (int k = 0; k < 3; ++k) { box[c][k] = entries[c].lo[k]; box[c][3 + k] = entries[c].hi[k]; }
+            if (entries[c].ref & RT_REF_LEAF_BIT) refs[c] = entries[c].ref;
+            else {
+                refs[c] = new_node();
+                jobs.push_back({entries[c].ref, refs[c], pending, job.depth + 1});
+            }
+        }
+        float4* q = &nodes4[8 * (size_t)job.slot4];
+        // two boxes per three float4, as in the binary layout
+        q[0] = f4(box[0][0], box[0][1], box[0][2], box[0][3]); q[1] = f4(box[0][4], box[0][5], box[1][0], box[1][1]);
+        q[2] = f4(box[1][2], box[1][3], box[1][4], box[1][5]);
+        q[3] = f4(box[2][0], box[2][1], box[2][2], box[2][3]); q[4] = f4(box[2][4], box[2][5], box[3][0], box[3][1]);
+        q[5] = f4(box[3][2], box[3][3], box[3][4], box[3][5]);
+        q[6] = f4(bits(refs[0]), bits(refs[1]), bits(refs[2]), bits(refs[3]));
+    }
     return RT_OK;
 }
 
@@ -323,11 +389,12 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device_id, RtScene**
         }
         o.material = t.material;
     }
-    std::vector<float4> nodes, hot, cold;
+    std::vector<float4> nodes, nodes4, hot, cold;
     std::vector<MeshLayout> layouts(desc->n_meshes);
-    uint32_t stack_entries = 1;
+    uint32_t stack_entries = 1, stack_entries4 = 1;
     for (uint32_t mi = 0; mi < desc->n_meshes; ++mi) {
         int rc = layout_mesh(desc, mi, nodes, hot, cold, &layouts[mi]);
+        if (rc == RT_OK) rc = collapse_mesh(nodes, mi, &layouts[mi], nodes4);
         if (rc != RT_OK) return rc;
     }
     std::vector<DInstance> instances(desc->n_mesh_instances);
@@ -345,6 +412,7 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device_id, RtScene**
         memcpy(o.root_lo, ml.root_lo, 12);
         memcpy(o.root_hi, ml.root_hi, 12);
         o.root_ref = ml.root_ref;
+        o.root_ref4 = ml.root_ref4;
         o.material_override = in.material_override;
         // Moeller-Trumbore's t carries a rounding error of at most about 10 eps K (t + D) / |a| with
         // K = |e1||e2|, D = |e1|+|e2| and |a| >= 1e-5 (intersect.rs:152-153): below 2^-7 (t + D) for
@@ -361,6 +429,7 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device_id, RtScene**
         if (!(o.world_guard == o.world_guard) || o.world_guard > 1e30f) o.prunable = 0;
         instance_world_box(in, ml, std::sqrt(fro), &o);
         if (ml.stack_need > stack_entries) stack_entries = ml.stack_need;
+        if (ml.stack_need4 > stack_entries4) stack_entries4 = ml.stack_need4;
     }
     if (stack_entries > RT_BVH_STACK_LEN)
         return fail(RT_ERR_BVH_TOO_DEEP, "a mesh BVH can need %u traversal stack entries; the reference's ArrayVec holds %d (intersect.rs:240)",
@@ -382,7 +451,8 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device_id, RtScene**
     s->d.background = desc->background;
     s->d.n_lights = desc->n_lights; s->d.n_planes = desc->n_planes; s->d.n_spheres = desc->n_spheres;
     s->d.n_triangles = desc->n_triangles; s->d.n_instances = desc->n_mesh_instances;
-    s->d.stack_entries = stack_entries;
+    s->d.stack_entries = stack_entries4;
+    s->d.stack_lds = std::min<uint32_t>(stack_entries4, RT_STACK_LDS_MAX);
     // range tree over the instances' culling boxes (see DScene), for scenes where a linear scan per ray hurts
     std::vector<float4> range_nodes;
     std::vector<float> range_limits;
@@ -436,13 +506,13 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device_id, RtScene**
         (rc = upload(s, planes, &s->d.planes)) || (rc = upload(s, spheres, &s->d.spheres)) ||
         (rc = upload(s, triangles, &s->d.triangles)) || (rc = upload(s, instances, &s->d.instances)) ||
         (rc = upload(s, range_nodes, &s->d.range_nodes)) || (rc = upload(s, range_limits, &s->d.range_limits)) ||
-        (rc = upload(s, nodes, &s->d.nodes)) || (rc = upload(s, hot, &s->d.tri_hot)) || (rc = upload(s, cold, &s->d.tri_cold)))
+        (rc = upload(s, nodes, &s->d.nodes)) || (rc = upload(s, nodes4, &s->d.nodes4)) || (rc = upload(s, hot, &s->d.tri_hot)) || (rc = upload(s, cold, &s->d.tri_cold)))
         return bail(rc);
     // five blocks per compute unit for the list kernels (measured on the 1080p bunnies frame: 4: 3.02 ms, 5: 2.93 ms,
     // 6: 2.94 ms with rt_shade squeezed into 80 registers, 8: 3.6 ms)
     s->list_blocks = (uint32_t)s->n_cus * 5;
     if (const char* env = getenv("RT_LIST_BLOCKS_PER_CU")) { int v = atoi(env); if (v >= 1 && v <= 8) s->list_blocks = (uint32_t)(s->n_cus * v); }
-    int bpc = rt_query_traverse_blocks_per_cu(s->list_blocks + 1, stack_entries);
+    int bpc = rt_query_traverse_blocks_per_cu(s->list_blocks + 1, s->d.stack_lds);
     if (bpc < 1) return bail(fail(RT_ERR_DEVICE, "the traversal kernel does not fit a compute unit"));
     if (const char* env = getenv("RT_BLOCKS_PER_CU")) { int v = atoi(env); if (v >= 1 && v <= bpc) bpc = v; }
     s->traverse_blocks = (uint32_t)(s->n_cus * bpc);
@@ -529,7 +599,7 @@ struct FrameSizes { size_t pixel_clear_bytes = 0, counter_words = 0, stats_words
 // the static scratch array for rt_render_device_noalloc.
 template <class Take>
 static int carve_frame(uint32_t n_pixels, uint32_t n_lights, uint32_t blocks, uint64_t capacity, uint32_t seg_min, bool aux,
-                       Take&& take, DFrame* out, FrameSizes* sz) {
+                       uint32_t spill_entries, uint32_t spill_lanes, Take&& take, DFrame* out, FrameSizes* sz) {
     DFrame& f = *out;
     memset(&f, 0, sizeof(f));
     f.n_seg = blocks + 1;
@@ -565,6 +635,8 @@ static int carve_frame(uint32_t n_pixels, uint32_t n_lights, uint32_t blocks, ui
         (rc = get(3 * hit_slots, &f.hits[0])) || (rc = get(3 * hit_slots, &f.hits[1])))
         return rc;
     f.shadow_base = (uint32_t)ray_slots;
+    f.spill_lanes = spill_lanes;
+    if (spill_entries && (rc = get((size_t)spill_entries * spill_lanes, &f.spill))) return rc;
     unsigned int* c = counters;
     f.ray_counts[0] = c; c += f.n_seg;   f.ray_counts[1] = c; c += f.n_seg;
     f.item_counts = c; c += f.n_seg;     f.fat_counts = c; c += f.n_seg;     f.slow_counts = c; c += f.n_seg;
@@ -627,7 +699,8 @@ static int ensure_frame(RtScene* s, const Geometry& g, uint32_t max_depth, bool 
             s->frame_allocs.push_back(*p);
             return (int)RT_OK;
         };
-        int rc = carve_frame(g.n_pixels, s->d.n_lights, blocks, capacity, seg_min, aux, take, &s->f, &sz);
+        int rc = carve_frame(g.n_pixels, s->d.n_lights, blocks, capacity, seg_min, aux, s->d.stack_entries - s->d.stack_lds,
+                             s->traverse_blocks * 256u, take, &s->f, &sz);
         if (rc) return rc;
         s->stats_words = sz.stats_words;
         s->counter_words = sz.counter_words;
@@ -701,7 +774,8 @@ static int enqueue_frame(RtScene* s, const RtRenderParams* p, bool sharded, bool
             return (int)RT_OK;
         };
         const uint64_t capacity = std::max<uint64_t>((uint64_t)8 * g.n_pixels, 4096);
-        if ((rc = carve_frame(g.n_pixels, s->d.n_lights, blocks, capacity, 64u, false, take, &f, &sz))) return rc;
+        if ((rc = carve_frame(g.n_pixels, s->d.n_lights, blocks, capacity, 64u, false, s->d.stack_entries - s->d.stack_lds,
+                              s->traverse_blocks * 256u, take, &f, &sz))) return rc;
         if (used > RT_NOALLOC_SCRATCH_BYTES)
             return fail(RT_ERR_OUT_OF_RANGE,
                         "rt_render_device_noalloc: %u pixels with %u lights need %llu bytes of scratch, the static array holds %llu; "

@@ -20,6 +20,7 @@
 struct float4 { float x, y, z, w; };
 #endif
 
+#define RT_STACK_LDS_MAX 16         // traversal stack entries per lane kept in LDS
 #define RT_MAX_DEPTH_LIMIT 63      // depth is carried in 6 bits of a ray record
 #define RT_MAX_PIXELS_PER_SHARD (1u << 25)
 #define RT_META_RAY_LIMIT 0x7FFFFFFFull   // ray slots are 31-bit numbers
@@ -53,6 +54,7 @@ struct DInstance {
     DMat34 rotation_scale;
     float root_lo[3], root_hi[3];   // AABB of the mesh's root node
     uint32_t root_ref;              // child reference of the root (see DScene::nodes), RT_REF_NONE for an empty mesh
+    uint32_t root_ref4;             // the same for the 4-wide tree (DScene::nodes4): what the BVH walk starts from
     int32_t material_override;      // -1 = none
     uint32_t prunable;              // 1: distance pruning and near-first ordering are provably result-preserving
     float prune_abs;                // absolute slack (mesh-local units) added to every pruning comparison
@@ -82,7 +84,8 @@ struct DInstance {
 struct DScene {
     RtBackground background;
     uint32_t n_lights, n_planes, n_spheres, n_triangles, n_instances;
-    uint32_t stack_entries;      // per-lane traversal stack entries any mesh can need (<= RT_BVH_STACK_LEN)
+    uint32_t stack_entries;      // per-lane traversal stack entries a walk of any mesh's 4-wide tree can need
+    uint32_t stack_lds;          // how many of them live in LDS (the rest, rarely reached, in DFrame::spill)
     uint32_t all_cullable;       // every instance has a usable culling box (DInstance::cullable)
     // Scenes with many instances: a binary tree over index ranges of the instances (node 0 = all of them, children
     // split a range in the middle), each node with the union of its instances' culling boxes.  Visiting the left
@@ -104,6 +107,11 @@ struct DScene {
     //   nodes[4*i]   = (L.min.x, L.min.y, L.min.z, L.max.x)   nodes[4*i+1] = (L.max.y, L.max.z, R.min.x, R.min.y)
     //   nodes[4*i+2] = (R.min.z, R.max.x, R.max.y, R.max.z)   nodes[4*i+3] = (bits ref L, bits ref R, 0, 0)
     const float4* nodes;
+    // The same trees with every other level folded away, for the BVH walk: node i is 128 B, two to four entries in the
+    // order the reference's walk would reach them, unused entries have the reference RT_REF_NONE.
+    //   entry 0: nodes4[8*i]   = (min.xyz, max.x), nodes4[8*i+1].xy = max.yz      entry 1: nodes4[8*i+1].zw = min.xy, nodes4[8*i+2] = (min.z, max.xyz)
+    //   entries 2, 3: the same in nodes4[8*i+3 .. 8*i+5]                          nodes4[8*i+6] = bits of the four references
+    const float4* nodes4;
     // slot s: tri_hot[3*s] = (p0.xyz, e1.x), [3*s+1] = (e1.y, e1.z, e2.x, e2.y), [3*s+2] = (e2.z, fn.xyz)
     const float4* tri_hot;
     // slot s: tri_cold[3*s] = (n0.xyz, bits mesh_triangle_index), [3*s+1] = (n1.xyz, bits material), [3*s+2] = (n2.xyz, 0)
@@ -158,6 +166,8 @@ struct DFrame {
     unsigned int* slow_rays;         // ray slots rt_setup left to rt_setup_slow, segmented like the ray lists
     unsigned int* slow_counts;       // [n_seg]
     unsigned int* slow_flags;        // [RT_MAX_DEPTH_LIMIT + 2] set when a depth has such rays
+    uint2* spill;                    // traversal stack entries beyond DScene::stack_lds: entry e of walking lane g at [e * spill_lanes + g]
+    uint32_t spill_lanes;            // lanes of the BVH walk's grid
     unsigned int* chunk_counter;     // [RT_MAX_DEPTH_LIMIT + 2] input chunks of the BVH walk handed out so far, per depth
     float4* hits[2];                 // Phong-shaded hits waiting for their shadow rays, 3 float4 each
     unsigned int* hit_counts[2];     // [n_seg]

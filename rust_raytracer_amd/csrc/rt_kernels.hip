@@ -1068,7 +1068,7 @@ __global__ void __launch_bounds__(RT_ROOT_THREADS) rt_root(const DScene S, const
                 if (ss.is_shadow) thr = ss.directional ? RT_INF : ss.limit_world - (1.5f * slack_w + 6.103515625e-05f * (o_l1 + ss.limit_world));
                 q0 = make_float4(lr.o.x, lr.o.y, lr.o.z, root_tmin);
                 q1 = make_float4(lr.d.x, lr.d.y, lr.d.z, limit);
-                q2 = make_float4(1.0f / dn, thr, inst.prune_abs, __uint_as_float(inst.root_ref));
+                q2 = make_float4(1.0f / dn, thr, inst.prune_abs, __uint_as_float(inst.root_ref4));
                 q3 = make_float4(__uint_as_float(gi), __uint_as_float(ii | (fast ? RT_FAT_FAST : 0u)), __uint_as_float(item), 0.0f);
             }
         }
@@ -1108,12 +1108,16 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
     const uint32_t n_items = build_prefix(F.fat_counts, F.n_seg, F.seg_fat, F.ovf_fat, pre, scratch);
     const uint32_t lane = threadIdx.x & (RT_WAVE - 1);
     const uint32_t wave = threadIdx.x / RT_WAVE;
-    uint32_t* wave_stack = lds + F.n_seg + 1 + blockDim.x + wave * (2 * S.stack_entries * RT_WAVE);
+    uint32_t* wave_stack = lds + F.n_seg + 1 + blockDim.x + wave * (2 * S.stack_lds * RT_WAVE);
     uint32_t* stack = wave_stack + lane;
-    uint32_t* stack_t = stack + S.stack_entries * RT_WAVE;
+    uint32_t* stack_t = stack + S.stack_lds * RT_WAVE;
+    // entries beyond the LDS part (a walk that keeps many siblings pending at once: rare) live in device memory
+    uint2* spill = F.spill + (blockIdx.x * blockDim.x + threadIdx.x);
+    const uint32_t stack_lds = S.stack_lds;
+    const size_t spill_lanes = F.spill_lanes;
     // one record per lane for the pair that lane started: {key lo = triangle slot, key hi = bits of local t,
     // walkers still at work on the pair, "shadow proven"}; 16-byte aligned
-    uint32_t* recs = lds + ((F.n_seg + 1 + blockDim.x + (blockDim.x / RT_WAVE) * (2 * S.stack_entries * RT_WAVE) + 3u) & ~3u) +
+    uint32_t* recs = lds + ((F.n_seg + 1 + blockDim.x + (blockDim.x / RT_WAVE) * (2 * S.stack_lds * RT_WAVE) + 3u) & ~3u) +
                      wave * (4 * RT_WAVE);
     uint32_t* donor_list = scratch + wave * RT_WAVE;               // free again once the prefix table is built
     const uint32_t gwave = (blockIdx.x * blockDim.x + threadIdx.x) / RT_WAVE;
@@ -1138,7 +1142,7 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
     // whatever the wave does in between.
     uint32_t cur_ref = RT_REF_NONE;
     float cur_t = 0.0f;
-    float4 nd0 = make_float4(0, 0, 0, 0), nd1 = nd0, nd2 = nd0, nd3 = nd0;
+    float4 nd0 = make_float4(0, 0, 0, 0), nd1 = nd0, nd2 = nd0, nd3 = nd0, nd4 = nd0, nd5 = nd0, nd6 = nd0;
     Ray lr; lr.o = lr.d = mk(0, 0, 0);
     V3 inv = mk(0, 0, 0);
     bool fast = false;
@@ -1149,6 +1153,11 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
     unsigned long long tm[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long t_begin = clock64();
 #endif
+
+    auto stack_push = [&](uint32_t e, uint32_t ref, float t) {
+        if (e < stack_lds) { stack[e * RT_WAVE] = ref; stack_t[e * RT_WAVE] = __float_as_uint(t); }
+        else spill[(e - stack_lds) * spill_lanes] = make_uint2(ref, __float_as_uint(t));
+    };
 
     for (;;) {
         const unsigned long long idle_mask = __ballot(!running);
@@ -1166,7 +1175,7 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
         unsigned long long give_mask = 0;
         if (out_of_input && __popcll(idle_mask) >= RT_SHARE_IDLE && run_mask != 0) {
             can_give = running && fast && sp - base >= 1 && (sp - base >= 2 || cur_ref != RT_REF_NONE || pending_leaf != RT_REF_NONE) &&
-                       !(stack[base * RT_WAVE] & RT_REF_LEAF_BIT);
+                       base < stack_lds && !(stack[base * RT_WAVE] & RT_REF_LEAF_BIT);
             give_mask = __ballot(can_give);
         }
         // ---- service: once a quarter of the wave is idle, nobody is walking, or there is something to share ---
@@ -1238,7 +1247,8 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
                     cur_ref = __float_as_uint(q2.w);
                     cur_t = q0.w;
                     if (!(cur_ref & RT_REF_LEAF_BIT)) {
-                        nd0 = S.nodes[4 * cur_ref]; nd1 = S.nodes[4 * cur_ref + 1]; nd2 = S.nodes[4 * cur_ref + 2]; nd3 = S.nodes[4 * cur_ref + 3];
+                        const float4* nq = S.nodes4 + 8 * (size_t)cur_ref;
+                        nd0 = nq[0]; nd1 = nq[1]; nd2 = nq[2]; nd3 = nq[3]; nd4 = nq[4]; nd5 = nq[5]; nd6 = nq[6];
                     }
                     sp = 0; base = 0;
                     owner = lane;
@@ -1277,8 +1287,11 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
                     fast = true;
                     m_have = false; m_t = 0.0f; m_u = 0.0f; m_v = 0.0f; m_slot = 0;
                     cur_ref = wave_stack[s_base * RT_WAVE + src];           // an inner node: leaves are not given away
-                    cur_t = __uint_as_float(wave_stack[(S.stack_entries + s_base) * RT_WAVE + src]);
-                    nd0 = S.nodes[4 * cur_ref]; nd1 = S.nodes[4 * cur_ref + 1]; nd2 = S.nodes[4 * cur_ref + 2]; nd3 = S.nodes[4 * cur_ref + 3];
+                    cur_t = __uint_as_float(wave_stack[(stack_lds + s_base) * RT_WAVE + src]);
+                    {
+                        const float4* nq = S.nodes4 + 8 * (size_t)cur_ref;
+                        nd0 = nq[0]; nd1 = nq[1]; nd2 = nq[2]; nd3 = nq[3]; nd4 = nq[4]; nd5 = nq[5]; nd6 = nq[6];
+                    }
                     sp = 0; base = 0;
                     running = true;
                 }
@@ -1360,36 +1373,51 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
                 if (cur_ref & RT_REF_LEAF_BIT) {
                     if ((cur_ref >> RT_REF_COUNT_SHIFT) & 7u) pending_leaf = cur_ref;
                 } else {
-                    float tl, tr;
-                    bool hl = slab(nd0.x, nd0.y, nd0.z, nd0.w, nd1.x, nd1.y, lr.o, inv, tl);
-                    bool hr = slab(nd1.z, nd1.w, nd2.x, nd2.y, nd2.z, nd2.w, lr.o, inv, tr);
-                    hl = hl && !(tl > cut);
-                    hr = hr && !(tr > cut);
-                    uint32_t rl = __float_as_uint(nd3.x), rr2 = __float_as_uint(nd3.y);
-                    // reference order: the right child first, then the left one (intersect.rs:253-256 pushes left, then
-                    // right, and pops); on the fast path the nearer child comes first instead
-                    if (fast && tl < tr) {
-                        uint32_t tu = rl; rl = rr2; rr2 = tu;
-                        float tf = tl; tl = tr; tr = tf;
-                        bool tb = hl; hl = hr; hr = tb;
+                    // up to four entries, stored in the order the reference's walk would reach them
+                    float t0, t1, t2, t3;
+                    const bool h0 = slab(nd0.x, nd0.y, nd0.z, nd0.w, nd1.x, nd1.y, lr.o, inv, t0);
+                    const bool h1 = slab(nd1.z, nd1.w, nd2.x, nd2.y, nd2.z, nd2.w, lr.o, inv, t1);
+                    const bool h2 = slab(nd3.x, nd3.y, nd3.z, nd3.w, nd4.x, nd4.y, lr.o, inv, t2);
+                    const bool h3 = slab(nd4.z, nd4.w, nd5.x, nd5.y, nd5.z, nd5.w, lr.o, inv, t3);
+                    uint32_t r0 = (h0 && !(t0 > cut)) ? __float_as_uint(nd6.x) : RT_REF_NONE;
+                    uint32_t r1 = (h1 && !(t1 > cut)) ? __float_as_uint(nd6.y) : RT_REF_NONE;
+                    uint32_t r2 = (h2 && !(t2 > cut)) ? __float_as_uint(nd6.z) : RT_REF_NONE;
+                    uint32_t r3 = (h3 && !(t3 > cut)) ? __float_as_uint(nd6.w) : RT_REF_NONE;
+                    // on the fast path the nearest entry comes first (a sorting network over the entry distances; the
+                    // order only decides how soon the pruning bites); otherwise the stored order is kept
+                    if (fast) {
+                        t0 = r0 == RT_REF_NONE ? RT_INF : t0; t1 = r1 == RT_REF_NONE ? RT_INF : t1;
+                        t2 = r2 == RT_REF_NONE ? RT_INF : t2; t3 = r3 == RT_REF_NONE ? RT_INF : t3;
+#define RT_CSWAP(ta, ra, tb, rb) { const bool sw = tb < ta; const float tt = sw ? ta : tb; ta = sw ? tb : ta; tb = tt; \
+                                   const uint32_t rt_ = sw ? ra : rb; ra = sw ? rb : ra; rb = rt_; }
+                        RT_CSWAP(t0, r0, t1, r1) RT_CSWAP(t2, r2, t3, r3) RT_CSWAP(t0, r0, t2, r2) RT_CSWAP(t1, r1, t3, r3) RT_CSWAP(t1, r1, t2, r2)
+#undef RT_CSWAP
                     }
-                    if (hr) {
-                        next_ref = rr2; next_t = tr;
-                        if (hl) { stack[sp * RT_WAVE] = rl; stack_t[sp * RT_WAVE] = __float_as_uint(tl); ++sp; }
-                    } else if (hl) {
-                        next_ref = rl; next_t = tl;
-                    }
+                    // go on with the first entry that passed, the others wait on the stack, the last one deepest
+                    const uint32_t first = r0 != RT_REF_NONE ? 0u : r1 != RT_REF_NONE ? 1u : r2 != RT_REF_NONE ? 2u : r3 != RT_REF_NONE ? 3u : 4u;
+                    if (r3 != RT_REF_NONE && first < 3u) { stack_push(sp, r3, t3); ++sp; }
+                    if (r2 != RT_REF_NONE && first < 2u) { stack_push(sp, r2, t2); ++sp; }
+                    if (r1 != RT_REF_NONE && first < 1u) { stack_push(sp, r1, t1); ++sp; }
+                    next_ref = first == 0u ? r0 : first == 1u ? r1 : first == 2u ? r2 : first == 3u ? r3 : RT_REF_NONE;
+                    next_t = first == 0u ? t0 : first == 1u ? t1 : first == 2u ? t2 : t3;
                 }
             }
             // what this lane looks at next: the child chosen above, else the top of its stack
             if (next_ref == RT_REF_NONE && sp != base) {
                 --sp;
-                next_ref = stack[sp * RT_WAVE];
-                next_t = __uint_as_float(stack_t[sp * RT_WAVE]);
+                if (sp < stack_lds) {
+                    next_ref = stack[sp * RT_WAVE];
+                    next_t = __uint_as_float(stack_t[sp * RT_WAVE]);
+                } else {
+                    const uint2 e = spill[(sp - stack_lds) * spill_lanes];
+                    next_ref = e.x;
+                    next_t = __uint_as_float(e.y);
+                }
             }
             cur_ref = next_ref; cur_t = next_t;
             if (cur_ref != RT_REF_NONE && !(cur_ref & RT_REF_LEAF_BIT)) {
-                nd0 = S.nodes[4 * cur_ref]; nd1 = S.nodes[4 * cur_ref + 1]; nd2 = S.nodes[4 * cur_ref + 2]; nd3 = S.nodes[4 * cur_ref + 3];
+                const float4* nq = S.nodes4 + 8 * (size_t)cur_ref;
+                nd0 = nq[0]; nd1 = nq[1]; nd2 = nq[2]; nd3 = nq[3]; nd4 = nq[4]; nd5 = nq[5]; nd6 = nq[6];
             }
         }
         if (running && pending_leaf == RT_REF_NONE && cur_ref == RT_REF_NONE && sp == base) {
@@ -1751,7 +1779,7 @@ extern "C" hipError_t rt_launch_level(const DScene* S, const DFrame* F, uint32_t
         hipLaunchKernelGGL(rt_root, dim3(blocks), dim3(RT_ROOT_THREADS), lds, stream, *S, *F, level);
     if (marks) (void)hipEventRecord(marks[2], stream);
     if (S->n_instances > 0)
-        hipLaunchKernelGGL(rt_traverse, dim3(traverse_blocks), dim3(RT_BLOCK_THREADS), traverse_lds_bytes(F->n_seg, S->stack_entries),
+        hipLaunchKernelGGL(rt_traverse, dim3(traverse_blocks), dim3(RT_BLOCK_THREADS), traverse_lds_bytes(F->n_seg, S->stack_lds),
                            stream, *S, *F, level);
 #ifdef RT_STATS
     if (stop && level == (uint32_t)atoi(stop)) return hipGetLastError();
