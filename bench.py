@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Headline benchmark: Mrays/s (primary + secondary) on reflective_bunnies at 1920x1080.
 
-One step = one frame of the workload.  With N ranks (one per GPU) the frame is tile-sharded: rank r
-renders the 32x32 tiles t with t % N == r of the same frame, the shard buffers are all-gathered over
-RCCL and every rank assembles the frame - the total work is fixed, so scaling is "strong".
+One step = one frame of the workload.  With N ranks (one per GPU) every frame is tile-sharded: rank r
+renders the 32x32 tiles t with t % N == r, the shard buffers are all-gathered over RCCL and every rank
+assembles the frame - the total work is fixed, so scaling is "strong".
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
@@ -11,8 +11,11 @@ RCCL and every rank assembles the frame - the total work is fixed, so scaling is
 
 The timed frames are rendered the way a renderer with a queue of frames would: --views-per-pass frames travel through
 the recursion depths together (rt_scene_set_views; by default up to eight 1080p frames' worth of pixels per rank), and a
-rank keeps --frames-in-flight (default 3) such passes queued, each on its own scene handle and stream.  `value` is
-that rate; the "sequential" object of the JSON line is the rate with one frame at a time.
+rank keeps --frames-in-flight (default 3) such passes queued, each on its own scene handle and stream.  Every frame in
+flight has its own camera: the scene's camera turned a little further from frame to frame (a camera drag), so no two
+frames of a pass trace the same rays; `value` counts the rays of the frames actually rendered.  The timed region of
+exactly --steps frames is repeated --repeats times and the median is reported.  The "sequential" object of the JSON
+line is the rate with one frame at a time at the scene's own camera.
 
 Rank 0 prints one JSON line.  The scene's bunny.obj is not part of the reference repository; a
 deterministic stand-in of 81 920 triangles is generated (rust_raytracer_amd/meshes.py) unless a real
@@ -42,35 +45,47 @@ WORKLOADS = {
     "instance_grid_10m_4k": ("synthetic:grid=16,meshes=128,level=6", 3840, 2160, 10),
 }
 
-# Algorithmic work of the reference's un-pruned traversal (what intersect.rs would execute), per
-# unit of the metric (one ray = one Scene::intersect call), counted by the oracle:
-#   bytes = 32*aabb_tests + 36*mesh_triangle_tests + 48*mesh_hits + 256*instance_transforms + 3*W*H
-#   flops = 27*aabb_tests + 57*(mesh_triangle_tests + triangle_tests) + 40*sphere_tests + 14*plane_tests
-#           + 90*instance_transforms + 60*light_shades
-# The BVH walk kernel (rt_traverse) owns the aabb_tests and mesh_triangle_tests terms; the instance
-# transforms and analytic primitives belong to rt_setup, normals and light sums to rt_shade.
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E
-FP32_NO_FMA_PEAK_TFLOPS = 78.6   # 157.3 TFLOP/s vector FP32 counts an FMA as two; contraction is forbidden here
+# 157.3 TFLOP/s vector FP32 counts an FMA as two operations; contraction is forbidden here (bit-exact hit decisions), so the
+# usable vector peak is one operation per lane and issue slot
+FP32_NO_FMA_PEAK_TFLOPS = 78.6
+# Operations of the two tests of the BVH walk, counted as the reference's arithmetic spells them out:
+#   box (AABB::intersect, intersect.rs:185-226): 6 sub + 6 mul + 12 min/max + 3 compares               = 27
+#   triangle (Triangle::intersect, intersect.rs:141-166): 2 cross (18) + 4 dot (20) + 2 sub (6) + 1 div + 3 mul + compares = 57
+FLOPS_PER_BOX_TEST = 27
+FLOPS_PER_TRIANGLE_TEST = 57
+BOXES_PER_NODE_VISIT = 4         # the device walk tests the four entries of a 4-wide node at every visit
 
 
-def algorithmic_work(counters, width, height):
+def reference_walk_work(counters):
+    """Work of the reference's own un-pruned walk (what intersect.rs would execute for this frame), counted by the
+    oracle: not what the device does - its walk is pruned - but the yardstick a CPU renderer is held to."""
     from rust_raytracer_amd import abi
     c = {n: int(v) for n, v in zip(abi.COUNTER_NAMES, counters)}
-    walk_bytes = 32 * c["aabb_tests"] + 36 * c["mesh_triangle_tests"]
-    walk_flops = 27 * c["aabb_tests"] + 57 * c["mesh_triangle_tests"]
-    nbytes = walk_bytes + 48 * c["mesh_hits"] + 256 * c["instance_transforms"] + 3 * width * height
-    flops = (walk_flops + 57 * c["triangle_tests"] + 40 * c["sphere_tests"] + 14 * c["plane_tests"]
-             + 90 * c["instance_transforms"] + 60 * c["light_shades"])
-    return {"bytes": nbytes, "flops": flops, "walk_bytes": walk_bytes, "walk_flops": walk_flops}
+    return {"bytes": 32 * c["aabb_tests"] + 36 * c["mesh_triangle_tests"],
+            "flops": FLOPS_PER_BOX_TEST * c["aabb_tests"] + FLOPS_PER_TRIANGLE_TEST * c["mesh_triangle_tests"]}
+
+
+def list_kernel_bytes(counts, n_lights):
+    """Bytes the two list kernels have to move per frame (ray records 32 B, candidate keys 8 B, hit records 48 B, colour
+    sums 24 B), from the frame's ray counts: what each record costs once written and once read."""
+    rays, primary, shadow, reflected, transmitted = (int(x) for x in counts[:5])
+    listed = primary + reflected + transmitted          # rays of the segmented lists; the rest are shadow rays
+    hits = shadow // max(n_lights, 1)
+    setup = rays * (32 + 8)                             # every ray read, its key written
+    shade = listed * (32 + 8) + hits * 48 + shadow * 32 + (reflected + transmitted) * 32 + listed * 24 \
+        + hits * (48 + 8 * n_lights + 24)               # ... and the Phong pass: hit record, shadow keys, colour sums
+    return {"rt_setup": setup, "rt_shade": shade}
 
 
 def cpu_baseline(scene_path, model_dir, width, height, max_depth, budget_s=15.0):
     """The CPU oracle (C++ restatement of the reference renderer, row-parallel like native_app's
-    rayon loop) timed on this host; also returns its un-pruned traversal statistics."""
+    rayon loop) timed on this host with every core the process may use; also returns its un-pruned traversal
+    statistics."""
     from oracle import orc
     s = orc.OracleScene.from_file(scene_path, model_dir)
     s.resize(width, height)
-    cores = min(len(os.sched_getaffinity(0)), 16)
+    cores = len(os.sched_getaffinity(0))
     t0 = time.perf_counter()
     r = s.render(max_depth, threads=cores, aux=False)
     dt = time.perf_counter() - t0
@@ -85,8 +100,10 @@ def cpu_baseline(scene_path, model_dir, width, height, max_depth, budget_s=15.0)
         frames += 1
     rays = int(r["counters"][0])
     return {"value": rays / best / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": "%d full %dx%d frames of the workload (%.2f s best, %d rays each), C++ oracle, %d threads"
-                      % (frames, width, height, best, rays, cores)}, r["counters"]
+            "host_cpus": os.cpu_count(),
+            "sample": "%d full %dx%d frames of the workload at the scene's own camera (%.2f s best, %d rays each), C++ oracle, "
+                      "%d threads = every core this process may run on (os.cpu_count() of the host: %d)"
+                      % (frames, width, height, best, rays, cores, os.cpu_count())}, r["counters"]
 
 
 def main():
@@ -94,18 +111,21 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=48)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--repeats", type=int, default=7, help="times the timed region of --steps frames is run; the median is reported")
     ap.add_argument("--workload", default="reflective_bunnies_1080p", choices=sorted(WORKLOADS))
     ap.add_argument("--model-dir", default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--frames-in-flight", type=int, default=3,
-                    help="independent frames a rank keeps queued (own scene handle, stream and buffers each); 1 = one after the other")
+                    help="independent passes a rank keeps queued (own scene handle, stream and buffers each); 1 = one after the other")
     ap.add_argument("--views-per-pass", type=int, default=0,
                     help="frames that travel through the recursion depths together (rt_scene_set_views); 0 = chosen from --steps and --gpus")
+    ap.add_argument("--same-camera", action="store_true", help="every frame in flight uses the scene's own camera (the round-1 schedule)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="all ranks share cuda:0 and gather over gloo: checks the N>1 code path on a one-GPU box, not a measurement")
-    ap.add_argument("--watchdog", type=int, default=900, help="seconds after which a stuck run prints its stacks and exits (0 = off)")
+    ap.add_argument("--watchdog", type=int, default=900, help="seconds after which a stuck run prints its stacks and exits non-zero (0 = off)")
     args = ap.parse_args()
     if args.watchdog:
+        # a gather that never completes must end the run with a failure, not hang the box: dump the stacks and _exit(1)
         import faulthandler
         faulthandler.dump_traceback_later(args.watchdog, exit=True)
 
@@ -156,22 +176,37 @@ def main():
     host.resize_screen(width, height)
     m, w, h = host.camera()
     n_tris = host.desc().n_mesh_triangles
+    n_lights = host.desc().n_lights
 
-    # A frame is a chain of short dependent launches (five per recursion depth), so one frame alone leaves the
-    # chip partly idle at every link.  A rank therefore keeps `depth` frames queued, as a renderer producing an
+    # A frame is a chain of short dependent launches (four per recursion depth), so one frame alone leaves the
+    # chip partly idle at every link.  A rank therefore keeps `depth` passes queued, as a renderer producing an
     # animation or a batch of views does: slot k has its own scene handle (own ray lists), stream and output buffers,
-    # frame i goes to slot i % depth.  Every frame is still rendered completely, gathered and assembled.
+    # pass i goes to slot i % depth.  Every frame is still rendered completely, gathered and assembled.
     depth = max(1, args.frames_in_flight)
     # Frames of one pass share every launch (rt_scene_set_views): the fixed cost of a recursion depth - launches, prefix
     # tables, the longest BVH walk - is paid once for all of them, which matters most for the small shards of many ranks.
     views = args.views_per_pass
     if views <= 0:
-        # as many as make eight 1080p frames' worth of pixels per rank (4: 9.7, 8: 10.4, 12: 10.3 Grays/s on one GPU),
-        # leaving at least two passes to overlap
+        # as many as make eight 1080p frames' worth of pixels per rank, leaving at least two passes to overlap
         cap = max(1, min(abi.RT_MAX_VIEWS, 8 * 1920 * 1080 * world // (w * h)))
         views = max([v for v in range(1, cap + 1) if args.steps // v >= 2] or [1])
     views = max(1, min(views, abi.RT_MAX_VIEWS, max(args.steps, 1)))
     passes, leftover = divmod(args.steps, views)       # the frames that do not fill a pass get a smaller pass of their own
+
+    # One camera per frame in flight: camera 0 is the scene's own, camera k the same turned by a drag of k * 12 pixels
+    # (Scene::turn_camera, scene.rs:76-97), alternately to the left and to the right.
+    n_cameras = depth * views + leftover
+    position0, orientation0 = host.camera_pose()
+    cameras = [np.asarray(m, dtype=np.float32).reshape(16)]
+    for k in range(1, n_cameras):
+        if args.same_camera:
+            cameras.append(cameras[0])
+            continue
+        host.set_camera_pose(position0, orientation0)
+        step = 12.0 * ((k + 1) // 2)
+        host.turn_camera(0.0, 0.0, step if k % 2 else -step, 0.0)
+        cameras.append(np.asarray(host.camera()[0], dtype=np.float32).reshape(16))
+    host.set_camera_pose(position0, orientation0)
 
     def host_staged_gather(gathered, shard):
         # Rehearsal only.  gloo's own device path puts high-priority streams behind events, and with two processes
@@ -183,12 +218,13 @@ def main():
         gathered.copy_(everyone)
 
     class Slot:
-        """One pass in flight: a scene handle (own ray lists), a stream and the buffers of `views` frames."""
+        """One pass in flight: a scene handle (own ray lists), a stream and the buffers of its frames, one per camera."""
 
-        def __init__(self, views, dev=None, stream=None):
-            self.views = views
+        def __init__(self, cams, dev=None, stream=None):
+            self.views = len(cams)
+            self.cams = cams
             self.dev = dev or native.DeviceScene(host.desc(), local_rank)
-            self.dev.set_views(np.tile(np.asarray(m, dtype=np.float32).reshape(1, 16), (views, 1)), w, h)
+            self.dev.set_views(np.stack(cams), w, h)
             self.stream = stream or torch.cuda.Stream()
             handle = self.stream.cuda_stream
             dev = self.dev
@@ -200,11 +236,14 @@ def main():
                 dev.assemble_shards(gathered.data_ptr(), frame.data_ptr(), world, stream=handle)
 
             self.sf = sharding.ShardedFrame(w, h, 3, rank, world, "cuda", render_shard, assemble,
-                                            host_staged_gather if args.rehearse_on_one_gpu else None, views=views)
+                                            host_staged_gather if args.rehearse_on_one_gpu else None, views=self.views)
 
         def step(self):
             with torch.cuda.stream(self.stream):       # the all-gather orders itself against torch's current stream
                 self.sf.step()
+
+        def frames(self):
+            return self.sf.frame.view(self.views, h, w, 3)
 
     # HIP gives a process four hardware queues and torch's pool streams take them in turn (stream i of the pool uses
     # queue i mod 4): passes only overlap when their streams sit on different queues (measured, 1/8 shards, three
@@ -212,10 +251,10 @@ def main():
     # So the streams are taken from the pool back to back, before anything else asks for one (with three of them the
     # fourth queue is left for the communicator's stream), and the pass of leftover frames shares a stream.
     streams = [torch.cuda.Stream() for _ in range(depth)]
-    slots = [Slot(views, stream=streams[k]) for k in range(depth)]
-    last_slot = Slot(leftover, stream=streams[passes % depth]) if leftover else None
+    slots = [Slot(cameras[k * views:(k + 1) * views], stream=streams[k]) for k in range(depth)]
+    last_slot = Slot(cameras[depth * views:], stream=streams[passes % depth]) if leftover else None
     every_slot = slots + ([last_slot] if last_slot else [])
-    dev, sf = slots[0].dev, slots[0].sf
+    dev = slots[0].dev
 
     def barrier():
         torch.cuda.synchronize()
@@ -224,44 +263,70 @@ def main():
         torch.cuda.synchronize()
 
     # Set-up, not warm-up: the first pass on a handle allocates its ray lists, the first gather creates the
-    # communicator, and a pass whose ray lists overflow is only noticed by the next one on that handle.
+    # communicator, and a pass whose ray lists overflow makes the next one on that handle allocate longer ones.
     for s in every_slot:
         for _ in range(2):
             s.step()
             torch.cuda.synchronize()
+        s.dev.last_ray_counts()                        # raises if the lists are still too short
     for k in range(-(-args.warmup // views)):          # the warm-up frames, in passes like the timed ones
         slots[k % depth].step()
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(passes):           # args.steps frames: `views` per pass ...
-        slots[k % depth].step()
+    regions = []
+    for _ in range(max(1, args.repeats)):
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(passes):           # args.steps frames: `views` per pass ...
+            slots[k % depth].step()
+        if last_slot:
+            last_slot.step()              # ... and the rest
+        barrier()
+        regions.append(time.perf_counter() - t0)
+    elapsed = float(np.median(regions))
+    # ray counts of every pass (raises if any frame since the set-up overflowed its ray lists: the report is sticky)
+    slot_counts = [s.dev.last_ray_counts().astype(np.int64)[:5] for s in every_slot]
+    counts = sum(slot_counts[k % depth] for k in range(passes))
     if last_slot:
-        last_slot.step()              # ... and the rest
-    barrier()
-    elapsed = time.perf_counter() - t0
-    for s in every_slot:
-        s.dev.last_ray_counts()       # raises if a frame of the timed region overflowed its ray lists
-    counts = dev.last_ray_counts().astype(np.int64) // views            # per frame (the views are the same frame)
-    frame_check = sf.frame[:h * w * 3].cpu().numpy().reshape(h, w, 3)
-    for other in every_slot:
-        assert torch.equal(other.sf.frame.view(other.views, -1), sf.frame[:h * w * 3].expand(other.views, -1)), \
-            "frames of the timed region differ"
+        counts = counts + slot_counts[-1]
 
-    # The same number of frames one at a time on one handle and one stream, for the latency of a single frame; the
-    # per-kernel pass further down runs this way too, so that a launch's duration is its own.
-    one = Slot(1, dev=dev, stream=slots[0].stream)       # slot 0's handle, from here on with a single view
+    # The same number of frames one at a time on one handle and one stream, at the scene's own camera, for the latency
+    # of a single frame; the per-kernel pass further down runs this way too, so that a launch's duration is its own.
+    one = Slot(cameras[:1], dev=dev, stream=slots[0].stream)       # slot 0's handle, from here on with a single view
     one.step(); one.step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one.step()
-    barrier()
-    elapsed_sequential = time.perf_counter() - t0
+    sequential = []
+    for _ in range(3):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one.step()
+        barrier()
+        sequential.append(time.perf_counter() - t0)
+    elapsed_sequential = float(np.median(sequential))
     trace_ms = dev.last_trace_ms()
     frame_ms = dev.last_render_ms()
-    assert np.array_equal(one.sf.frame.cpu().numpy().reshape(h, w, 3), frame_check), "a frame rendered alone differs"
+    own_counts = dev.last_ray_counts().astype(np.int64)            # this rank's share of the frame at the scene's own camera
+    frame_check = one.frames()[0].cpu().numpy()
+    # every frame of the timed region against the same camera rendered alone, byte for byte
+    checked = 0
+    for s in every_slot:
+        got = s.frames().cpu().numpy()
+        for v in range(s.views):
+            if v == 0 or v == s.views - 1 or args.same_camera:
+                if np.array_equal(s.cams[v], cameras[0]):
+                    alone = frame_check
+                else:
+                    one.dev.set_views(s.cams[v].reshape(1, 16), w, h)
+                    one.step()
+                    torch.cuda.synchronize()
+                    alone = one.frames()[0].cpu().numpy()
+                assert np.array_equal(got[v], alone), "frame %d of pass slot %d differs from the same camera rendered alone on %d pixels" % (
+                    v, every_slot.index(s), int((got[v] != alone).any(axis=2).sum()))
+                checked += 1
+    one.dev.set_views(cameras[0].reshape(1, 16), w, h)
+    if not args.same_camera and n_cameras > 1:
+        assert len({s.frames()[v].cpu().numpy().tobytes() for s in every_slot for v in range(s.views)}) == n_cameras, \
+            "two cameras of the timed region gave the same frame"
 
-    # Per-kernel durations, live: the same steps once more with every launch of the four per-depth
+    # Per-kernel durations, live: the same steps once more with every launch of the per-depth
     # kernels bracketed by HIP events on the launch stream (outside the timed region above, so that
     # the event records do not touch `value`).
     kernel_ms = {k: [0.0, 0] for k in dev.LEVEL_KERNELS}
@@ -275,70 +340,94 @@ def main():
     barrier()
 
     t = torch.tensor([elapsed, elapsed_sequential], dtype=torch.float64, device="cuda")
-    rays = torch.tensor(counts[:5], dtype=torch.int64, device="cuda")
+    rays = torch.tensor(np.concatenate([counts, own_counts[:5], own_counts[[abi.RT_CTR_WALK_NODE_VISITS, abi.RT_CTR_WALK_TRIANGLE_TESTS]]]),
+                        dtype=torch.int64, device="cuda")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
     elapsed, elapsed_sequential = (float(x) for x in t.cpu())
     rays = rays.cpu().numpy()
+    region_rays, frame_rays, walk_nodes, walk_tris = rays[:5], rays[5:10], int(rays[10]), int(rays[11])
 
     if rank == 0:
-        rays_per_frame = int(rays[0])
-        value = rays_per_frame * args.steps / elapsed / 1e6
+        rays_per_frame = int(frame_rays[0])
+        value = int(region_rays[0]) / elapsed / 1e6
         out = {
             "metric": "Mrays/s (primary+secondary) at 1080p reflective_bunnies" if args.workload == "reflective_bunnies_1080p"
                       else "Mrays/s (primary+secondary) " + args.workload,
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "repeats": len(regions), "timed_region_s": elapsed, "timed_regions_s": [round(x, 6) for x in regions],
             "config": {"workload": args.workload, "scene": scene_file, "width": w, "height": h, "max_depth": max_depth,
                        "mesh": ("%d mesh triangles, procedural" % n_tris if scene_file.startswith("synthetic:") else
                                 "stand-in meshes (procedural, %d triangles) unless --model-dir holds the real ones" % n_tris)
                                if n_tris else "none",
-                       "rays_per_frame": rays_per_frame, "primary": int(rays[1]), "shadow": int(rays[2]),
-                       "reflected": int(rays[3]), "transmitted": int(rays[4]),
+                       "cameras": "every frame of the scene's own camera" if args.same_camera else
+                                  "%d distinct cameras: the scene's own and %d drags of it (12 pixels apart, both ways); %d of the "
+                                  "frames compared byte for byte with the same camera rendered alone" % (n_cameras, n_cameras - 1, checked),
+                       "rays_in_timed_region": int(region_rays[0]), "mean_rays_per_frame": int(region_rays[0]) / max(args.steps, 1),
+                       "rays_per_frame": rays_per_frame, "primary": int(frame_rays[1]), "shadow": int(frame_rays[2]),
+                       "reflected": int(frame_rays[3]), "transmitted": int(frame_rays[4]),
                        "frames_in_flight": depth * views, "passes_in_flight": depth, "views_per_pass": views,
                        "parallelism": ("tile-sharded x%d, scene replicated, %s" % (world, "REHEARSAL: ranks share one GPU, gloo"
                                        if args.rehearse_on_one_gpu else "RCCL all-gather")) if world > 1 else "single GPU"},
-            # one frame at a time (the next is issued behind the previous one on the same stream)
+            # one frame at a time at the scene's own camera (the next is issued behind the previous one on the same stream)
             "sequential": {"value": rays_per_frame * args.steps / elapsed_sequential / 1e6, "unit": "Mrays/s",
                            "ms_per_step": elapsed_sequential / args.steps * 1e3},
         }
-        baseline = None
         ref_counters = None
         if not args.no_cpu_baseline and world == 1:
             baseline, ref_counters = cpu_baseline(scene_path, model_dir, w, h, max_depth)
             out["cpu_baseline"] = baseline
             # the frame the GPU produced must agree with the oracle's ray statistics
-            assert [int(x) for x in ref_counters[:5]] == [int(x) for x in rays[:5]], "ray counts differ from the oracle"
-        # the dominant kernel is the BVH walk; its average launch duration comes from the events above
-        walk_ms, walk_launches = kernel_ms["rt_traverse"]
-        per_frame_launches = walk_launches // args.steps if args.steps else 0
-        avg_launch_ms = walk_ms / walk_launches if walk_launches else None
-        roofline = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                    "kernel": "rt_traverse", "launches_per_frame": per_frame_launches, "avg_launch_ms": avg_launch_ms,
-                    "kernels_ms_per_frame": {k: (v[0] / args.steps if args.steps else None) for k, v in kernel_ms.items()},
-                    "trace_ms_per_frame": trace_ms, "frame_kernel_ms": frame_ms}
-        if ref_counters is not None and walk_launches:
-            work = algorithmic_work(ref_counters, w, h)
-            # per launch: the walk's share of the per-ray figure x the rays one launch handles (a frame's rays
-            # spread over its launches)
-            roofline["achieved"] = work["walk_bytes"] / per_frame_launches / (avg_launch_ms * 1e-3) / 1e9
-            roofline["frac"] = roofline["achieved"] / HBM_PEAK_GBS
-            roofline["algorithmic_bytes_per_ray"] = work["walk_bytes"] / rays_per_frame
-            roofline["algorithmic_flops_per_ray"] = work["walk_flops"] / rays_per_frame
-            roofline["rays_per_launch"] = rays_per_frame / per_frame_launches
-            walk_tflops = work["walk_flops"] / per_frame_launches / (avg_launch_ms * 1e-3) / 1e12
-            roofline["valu"] = {"achieved": walk_tflops, "peak": FP32_NO_FMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": walk_tflops / FP32_NO_FMA_PEAK_TFLOPS}
-            # all kernels of the recursion depths against the whole per-ray figure
-            roofline["whole_trace"] = {"algorithmic_bytes_per_ray": work["bytes"] / rays_per_frame,
-                                       "algorithmic_flops_per_ray": work["flops"] / rays_per_frame,
-                                       "achieved_GBs": work["bytes"] / (trace_ms * 1e-3) / 1e9,
-                                       "achieved_TFLOPs": work["flops"] / (trace_ms * 1e-3) / 1e12}
+            assert [int(x) for x in ref_counters[:5]] == [int(x) for x in frame_rays], "ray counts differ from the oracle"
+
+        # ---- roofline of the dominant kernel: the per-depth kernel with the largest share of a frame rendered alone ----
+        per_frame_ms = {k: (v[0] / args.steps if args.steps else 0.0) for k, v in kernel_ms.items()}
+        dominant = max(per_frame_ms, key=per_frame_ms.get)
+        ms_sum, launches = kernel_ms[dominant]
+        per_frame_launches = launches // args.steps if args.steps else 0
+        avg_launch_ms = ms_sum / launches if launches else None
         traffic_file = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+        traffic = None
         if os.path.exists(traffic_file):
-            roofline["traffic"] = json.load(open(traffic_file)).get("hbm_bytes_per_launch")
+            traffic = json.load(open(traffic_file)).get("kernels", {}).get(dominant, {}).get("hbm_bytes_per_launch")
+        roofline = {"kernel": dominant, "launches_per_frame": per_frame_launches, "avg_launch_ms": avg_launch_ms,
+                    "kernels_ms_per_frame": per_frame_ms, "trace_ms_per_frame": trace_ms, "frame_kernel_ms": frame_ms,
+                    "traffic": traffic}
+        if launches:
+            seconds = avg_launch_ms * 1e-3
+            hbm = {"achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                   "what": "HBM-side bytes per launch from the PMC counters (profiles/traffic_%s.json) / the launch's duration" % args.workload}
+            if traffic:
+                hbm["achieved"] = traffic / seconds / 1e9
+                hbm["frac"] = hbm["achieved"] / HBM_PEAK_GBS
+            if dominant == "rt_traverse":
+                # the kernel's own counted work: the nodes its pruned walk visited (four box tests each) and the triangle tests it ran
+                flops = FLOPS_PER_BOX_TEST * BOXES_PER_NODE_VISIT * walk_nodes + FLOPS_PER_TRIANGLE_TEST * walk_tris
+                achieved = flops / per_frame_launches / seconds / 1e12
+                roofline.update({"bound": "valu", "achieved": achieved, "peak": FP32_NO_FMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": achieved / FP32_NO_FMA_PEAK_TFLOPS,
+                                 "work": {"node_visits_per_frame": walk_nodes, "triangle_tests_per_frame": walk_tris,
+                                          "flops_per_frame": flops, "flops_per_ray": flops / max(rays_per_frame, 1),
+                                          "counted_by": "the kernel itself (RT_CTR_WALK_*), %d flop per box test x %d boxes per node visit, "
+                                                        "%d per triangle test" % (FLOPS_PER_BOX_TEST, BOXES_PER_NODE_VISIT, FLOPS_PER_TRIANGLE_TEST)},
+                                 "hbm": hbm})
+                if ref_counters is not None:
+                    # for comparison only: the rate the reference's un-pruned walk would need to finish in the same time
+                    ref = reference_walk_work(ref_counters)
+                    roofline["reference_equivalent"] = {
+                        "GBs": ref["bytes"] / per_frame_launches / seconds / 1e9, "TFLOPs": ref["flops"] / per_frame_launches / seconds / 1e12,
+                        "what": "bytes and flops of the reference's UN-PRUNED walk (oracle-counted) / this kernel's time: an equivalent "
+                                "rate, not work done and no roofline fraction"}
+            else:
+                nbytes = list_kernel_bytes(frame_rays, n_lights)[dominant]
+                achieved = nbytes / per_frame_launches / seconds / 1e9
+                roofline.update({"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                                 "work": {"bytes_per_frame": nbytes, "bytes_per_ray": nbytes / max(rays_per_frame, 1),
+                                          "counted_by": "record sizes x the frame's ray counts (list_kernel_bytes in bench.py)"},
+                                 "measured_hbm": hbm})
         out["roofline"] = roofline
         out["frame_checksum"] = int(np.asarray(frame_check, dtype=np.uint64).sum())
         print(json.dumps(out))

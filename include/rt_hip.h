@@ -183,6 +183,10 @@ enum {
     RT_CTR_INSTANCE_TRANSFORMS,
     RT_CTR_MESH_HITS,         /* instance traversals that returned a hit (normals fetched) */
     RT_CTR_LIGHT_SHADES,      /* Raytracer::radiance calls */
+    /* what the device's own BVH walk did (pruned, 4-wide tree): nodes it visited - four box tests each - and triangle
+     * tests it ran; no counterpart in the reference's walk, which the five counters above describe */
+    RT_CTR_WALK_NODE_VISITS,
+    RT_CTR_WALK_TRIANGLE_TESTS,
     RT_N_COUNTERS
 };
 
@@ -190,7 +194,7 @@ typedef struct RtAux {              /* with several views (rt_scene_set_views): 
     uint32_t* prim_id;        /* W*H, row 0 = top, or NULL */
     uint32_t* instance_id;    /* W*H or NULL */
     uint8_t* flags;           /* W*H or NULL */
-    uint64_t counters[RT_N_COUNTERS];   /* the device path fills RT_CTR_RAYS..RT_CTR_TRANSMITTED, the rest stay 0 */
+    uint64_t counters[RT_N_COUNTERS];   /* the device path fills RT_CTR_RAYS..RT_CTR_TRANSMITTED and RT_CTR_WALK_*, the rest stay 0 */
 } RtAux;
 
 enum { RT_FORMAT_RGB8 = 0, RT_FORMAT_RGBA8 = 1 };
@@ -278,7 +282,7 @@ int rt_shard_bytes(const RtScene* scene, const RtRenderParams* params, uint64_t*
 int rt_assemble_shards(RtScene* scene, const RtRenderParams* params, const void* d_gathered, void* d_frame);
 
 /* Ray counts of the last rt_render / rt_render_device on this handle (waits for it to finish).
- * Fills RT_CTR_RAYS..RT_CTR_TRANSMITTED.  Fails with RT_ERR_OUT_OF_RANGE if a ray list overflowed in any
+ * Fills RT_CTR_RAYS..RT_CTR_TRANSMITTED and RT_CTR_WALK_*.  Fails with RT_ERR_OUT_OF_RANGE if a ray list overflowed in any
  * rt_render_device frame since the previous call of this function (such a frame's output is incomplete); every
  * overflow is reported once. */
 int rt_last_ray_counts(RtScene* scene, uint64_t counters[RT_N_COUNTERS]);

@@ -614,7 +614,7 @@ static int carve_frame(uint32_t n_pixels, uint32_t n_lights, uint32_t blocks, ui
     const size_t hit_slots = (size_t)blocks * f.seg_hits + f.ovf_hits;
     const size_t all_ray_slots = ray_slots + hit_slots * n_lights;      // + the shadow rays, see DFrame::rays
     if (all_ray_slots >= RT_META_RAY_LIMIT) return fail(RT_ERR_OUT_OF_RANGE, "a frame needs more than 2^31 ray slots per depth");
-    sz->stats_words = (size_t)blocks * 4 * 8;
+    sz->stats_words = (size_t)std::max<uint32_t>(blocks * 4, spill_lanes / 64) * 8;      // a row per wave of the largest grid
     // colour sums and poison words in one allocation, all counters in another: two clears per frame
     sz->pixel_clear_bytes = (size_t)3 * n_pixels * sizeof(long long) + (size_t)n_pixels * sizeof(unsigned int);
     sz->counter_words = 7 * (size_t)f.n_seg + 2 * (RT_MAX_DEPTH_LIMIT + 2) + sz->stats_words;
@@ -948,6 +948,8 @@ extern "C" int rt_last_ray_counts(RtScene* s, uint64_t counters[RT_N_COUNTERS]) 
     if (rc) return rc;
     for (int k = 0; k < RT_N_COUNTERS; ++k) counters[k] = 0;
     for (int k = 0; k < 5; ++k) counters[k] = sums[k];
+    counters[RT_CTR_WALK_NODE_VISITS] = sums[5];
+    counters[RT_CTR_WALK_TRIANGLE_TESTS] = sums[6];
     return RT_OK;
 }
 

@@ -171,7 +171,7 @@ struct DFrame {
     unsigned int* chunk_counter;     // [RT_MAX_DEPTH_LIMIT + 2] input chunks of the BVH walk handed out so far, per depth
     float4* hits[2];                 // Phong-shaded hits waiting for their shadow rays, 3 float4 each
     unsigned int* hit_counts[2];     // [n_seg]
-    unsigned int* wave_stats;        // [waves][8]: rays, primary, shadow, reflected, transmitted
+    unsigned int* wave_stats;        // [waves][8]: rays, primary, shadow, reflected, transmitted (rt_shade); 4-wide nodes visited, triangles tested (rt_traverse)
     // A list did not fit (the frame is then invalid): the kernels store the frame's sequence number here.  The host
     // only ever reads the word, so no report can be lost to a clear; frames of one handle run one after the other,
     // so the word names the latest frame that overflowed.

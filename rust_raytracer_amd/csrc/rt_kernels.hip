@@ -1148,6 +1148,7 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
     bool fast = false;
     float limit = RT_INF, prune_abs = 0.0f, shadow_thr = -RT_INF, inv_dn = 0.0f;
     bool m_have = false; float m_t = 0.0f, m_u = 0.0f, m_v = 0.0f; uint32_t m_slot = 0;
+    uint32_t n_node_visits = 0, n_triangle_tests = 0;      // this lane's share of the launch's work, for the statistics
 #ifdef RT_STATS
     uint32_t dbg_steps = 0;
     unsigned long long tm[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1316,6 +1317,7 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
                     const uint32_t first = pending_leaf & RT_REF_SLOT_MASK;
                     const uint32_t cnt = (pending_leaf >> RT_REF_COUNT_SHIFT) & 7u;
                     pending_leaf = RT_REF_NONE;
+                    n_triangle_tests += cnt;
                     bool improved = false;
                     // all of the leaf's triangles are fetched before the first test, so that the fetches overlap
                     // (entries past the leaf's count repeat its last triangle and are not tested)
@@ -1374,6 +1376,7 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
                     if ((cur_ref >> RT_REF_COUNT_SHIFT) & 7u) pending_leaf = cur_ref;
                 } else {
                     // up to four entries, stored in the order the reference's walk would reach them
+                    ++n_node_visits;
                     float t0, t1, t2, t3;
                     const bool h0 = slab(nd0.x, nd0.y, nd0.z, nd0.w, nd1.x, nd1.y, lr.o, inv, t0);
                     const bool h1 = slab(nd1.z, nd1.w, nd2.x, nd2.y, nd2.z, nd2.w, lr.o, inv, t1);
@@ -1424,6 +1427,12 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
             running = false;                                         // settled in the next service phase
             pending = true;
         }
+    }
+    // work statistics: every wave owns a row of F.wave_stats (no atomics)
+    {
+        uint32_t a = n_node_visits, b = n_triangle_tests;
+        for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
+        if (lane == 0 && (a | b)) { F.wave_stats[(size_t)gwave * 8 + 5] += a; F.wave_stats[(size_t)gwave * 8 + 6] += b; }
     }
 #ifdef RT_STATS
     tm[0] = clock64() - t_begin;

@@ -14,13 +14,14 @@ def per_kernel(d, counter):
 
 fetch, nf = per_kernel(sys.argv[1], 'FETCH_SIZE')
 write, nw = per_kernel(sys.argv[2], 'WRITE_SIZE')
-out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over 3 frames of " + (sys.argv[4] if len(sys.argv) > 4 else "reflective_bunnies 1920x1080 depth 10"),
+out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over 3 frames (one at a time) of the bench.py workload " + (sys.argv[4] if len(sys.argv) > 4 else "reflective_bunnies_1080p"),
        "correction": "FETCH_SIZE KiB x 1024 x 2 (gfx950 tallies 128-B requests as 64 B); WRITE_SIZE KiB x 1024", "kernels": {}}
 for k in fetch:
     fb = fetch[k] * 1024 * 2 / nf[k]
     wb = write.get(k, 0.0) * 1024 / max(nw.get(k, 1), 1)
     out["kernels"][k] = {"launches": nf[k], "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "hbm_bytes_per_launch": fb + wb}
-out["kernel"] = "rt_traverse"
-out["hbm_bytes_per_launch"] = out["kernels"]["rt_traverse"]["hbm_bytes_per_launch"]
+if "rt_traverse" in out["kernels"]:
+    out["kernel"] = "rt_traverse"
+    out["hbm_bytes_per_launch"] = out["kernels"]["rt_traverse"]["hbm_bytes_per_launch"]
 json.dump(out, open(sys.argv[3], 'w'), indent=1)
 print(json.dumps(out, indent=1))
