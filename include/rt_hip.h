@@ -281,6 +281,29 @@ int rt_shard_bytes(const RtScene* scene, const RtRenderParams* params, uint64_t*
  * frame to `d_frame`.  Stitches rows as web_app/src/main/model.ts:115-129 stitches worker rows. */
 int rt_assemble_shards(RtScene* scene, const RtRenderParams* params, const void* d_gathered, void* d_frame);
 
+/* ---- one frame over several GPUs, driven by one process -----------------------------------------------------------
+ * The reference's counterpart is its worker pool: N workers, each with its own copy of the Scene, render interleaved
+ * rows into their own buffers and one owner stitches them (web_app/src/main/model.ts:93-129,
+ * web_app/wasm/src/renderer.rs:68-76, web_app/src/worker/render_worker.ts:28,48-52).  rt_multi_create replicates the
+ * scene on every device of `device_ids` (all different), owns one stream per device and one RCCL communicator set
+ * (ncclCommInitAll); rt_multi_render lets device i render the tiles t with t % n_devices == i, moves the shard buffers
+ * with one ncclAllGather, assembles the frame on the first device and copies it to `out_pixels` (host memory, the
+ * layout of rt_render; with rt_multi_set_views n_views frames back to back).  Shard fields and `stream` of `params`
+ * must be unset.  The bytes equal rt_render's for any number of devices.  A frame whose ray lists overflow on some
+ * device is rendered again with longer lists, as rt_render does.
+ * To rehearse the schedule on a one-GPU machine `device_ids` may name the same device n times: the shards are then
+ * rendered one after the other on that GPU and the exchange is device-to-device copies instead of the collective. */
+typedef struct RtMulti RtMulti;
+int rt_multi_create(const RtSceneDesc* desc, const int* device_ids, int n_devices, RtMulti** out_renderer);
+int rt_multi_set_camera(RtMulti* renderer, const float screen_to_world[16], uint32_t width, uint32_t height);
+int rt_multi_set_views(RtMulti* renderer, const float* screen_to_world, uint32_t n_views, uint32_t width, uint32_t height);
+int rt_multi_render(RtMulti* renderer, const RtRenderParams* params, uint8_t* out_pixels);
+/* ray counts of the last frame summed over the devices; wall-clock milliseconds of the last rt_multi_render call
+ * (shards, exchange, assembly and the copy to the host) */
+int rt_multi_last_ray_counts(RtMulti* renderer, uint64_t counters[RT_N_COUNTERS]);
+int rt_multi_last_render_ms(RtMulti* renderer, float* out_ms);
+void rt_multi_destroy(RtMulti* renderer);
+
 /* Ray counts of the last rt_render / rt_render_device on this handle (waits for it to finish).
  * Fills RT_CTR_RAYS..RT_CTR_TRANSMITTED and RT_CTR_WALK_*.  Fails with RT_ERR_OUT_OF_RANGE if a ray list overflowed in any
  * rt_render_device frame since the previous call of this function (such a frame's output is incomplete); every

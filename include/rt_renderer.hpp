@@ -46,6 +46,23 @@ public:
             throw;
         }
     }
+    // The same renderer over several GPUs of this machine (rt_multi_*): the scene is replicated, every frame is cut
+    // into 32x32 tiles dealt round-robin to the devices and stitched on the first one - the worker pool of
+    // web_app/src/main/model.ts:93-129 with GPUs for workers.  The pictures are byte-identical to the one-device ones.
+    HipRenderer(uint32_t canvas_width, uint32_t canvas_height, const std::string& scene_path, const std::string& model_dir,
+                const std::vector<int>& device_ids) {
+        check(rt_host_scene_load(scene_path.c_str(), model_dir.c_str(), &host_));
+        try {
+            if (canvas_width != 0 && canvas_height != 0) check(rt_host_scene_resize_screen(host_, canvas_width, canvas_height));
+            RtSceneDesc desc;
+            check(rt_host_scene_desc(host_, &desc));
+            check(rt_multi_create(&desc, device_ids.data(), (int)device_ids.size(), &multi_));
+            push_camera();
+        } catch (...) {
+            release();
+            throw;
+        }
+    }
     HipRenderer(const HipRenderer&) = delete;
     HipRenderer& operator=(const HipRenderer&) = delete;
     ~HipRenderer() { release(); }
@@ -82,21 +99,15 @@ public:
             check(rt_host_scene_turn_camera(host_, drags[k][0], drags[k][1], drags[k][2], drags[k][3]));
             check(rt_host_scene_camera(host_, &views[(size_t)k * 16], &width_, &height_));
         }
-        check(rt_scene_set_views(scene_, views.data(), n, width_, height_));
-        RtRenderParams p{};
-        p.max_depth = max_depth_;
-        p.output_format = RT_FORMAT_RGB8;
-        p.shard_count = 1;
-        RtAux aux{};
-        check(rt_render(scene_, &p, canvases, &aux));
-        last_rays_ = aux.counters[RT_CTR_RAYS];
-        check(rt_last_render_ms(scene_, &last_ms_));
+        if (multi_) check(rt_multi_set_views(multi_, views.data(), n, width_, height_));
+        else check(rt_scene_set_views(scene_, views.data(), n, width_, height_));
+        draw(canvases, RT_FORMAT_RGB8);
         push_camera();                                     // back to one view: the camera after the last drag
     }
 
     // MAX_RAY_RECURSION_DEPTH (raytracer.rs:9) is a constant of the reference; here it can be set per renderer.
     void set_max_depth(uint32_t depth) { max_depth_ = depth; }
-    // primary + secondary rays and kernel milliseconds of the last render
+    // primary + secondary rays and milliseconds of the last render (kernels on one device; the whole call on several)
     uint64_t last_rays() const { return last_rays_; }
     float last_render_ms() const { return last_ms_; }
 
@@ -104,22 +115,36 @@ private:
     void push_camera() {
         float m[16];
         check(rt_host_scene_camera(host_, m, &width_, &height_));
-        check(rt_scene_set_camera(scene_, m, width_, height_));
+        if (multi_) check(rt_multi_set_camera(multi_, m, width_, height_));
+        else check(rt_scene_set_camera(scene_, m, width_, height_));
+    }
+    void draw(uint8_t* canvas, uint32_t format) {
+        RtRenderParams p{};
+        p.max_depth = max_depth_;
+        p.output_format = format;
+        if (multi_) {
+            check(rt_multi_render(multi_, &p, canvas));
+            uint64_t counters[RT_N_COUNTERS];
+            check(rt_multi_last_ray_counts(multi_, counters));
+            last_rays_ = counters[RT_CTR_RAYS];
+            check(rt_multi_last_render_ms(multi_, &last_ms_));
+        } else {
+            p.shard_count = 1;
+            RtAux aux{};
+            check(rt_render(scene_, &p, canvas, &aux));
+            last_rays_ = aux.counters[RT_CTR_RAYS];
+            check(rt_last_render_ms(scene_, &last_ms_));
+        }
     }
     void render_into(uint8_t* canvas, size_t len, uint32_t format, uint32_t channels) {
         if (len != (size_t)width_ * height_ * channels)
             throw Error(RT_ERR_INVALID_ARGUMENT, "canvas of " + std::to_string(len) + " bytes for a " + std::to_string(width_) + "x" +
                                                      std::to_string(height_) + " frame of " + std::to_string(channels) + " channels");
-        RtRenderParams p{};
-        p.max_depth = max_depth_;
-        p.output_format = format;
-        p.shard_count = 1;
-        RtAux aux{};
-        check(rt_render(scene_, &p, canvas, &aux));
-        last_rays_ = aux.counters[RT_CTR_RAYS];
-        check(rt_last_render_ms(scene_, &last_ms_));
+        draw(canvas, format);
     }
     void release() {
+        if (multi_) rt_multi_destroy(multi_);
+        multi_ = nullptr;
         if (scene_) rt_scene_destroy(scene_);
         if (host_) rt_host_scene_destroy(host_);
         scene_ = nullptr;
@@ -128,6 +153,7 @@ private:
 
     RtHostScene* host_ = nullptr;
     RtScene* scene_ = nullptr;
+    RtMulti* multi_ = nullptr;          // set instead of scene_ by the several-GPU constructor
     uint32_t width_ = 0, height_ = 0;
     uint32_t max_depth_ = RT_DEFAULT_MAX_DEPTH;
     uint64_t last_rays_ = 0;

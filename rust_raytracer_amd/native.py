@@ -17,7 +17,9 @@ EXPORTS = ["rt_scene_create", "rt_scene_set_camera", "rt_scene_set_views", "rt_r
            "rt_noalloc_scratch_bytes", "rt_shard_bytes",
            "rt_assemble_shards", "rt_last_ray_counts", "rt_last_render_ms", "rt_last_trace_ms", "rt_set_kernel_timing",
            "rt_last_kernel_ms", "rt_scene_destroy",
-           "rt_debug_set_queue_capacity", "rt_debug_last_regrown", "rt_last_error"]
+           "rt_debug_set_queue_capacity", "rt_debug_last_regrown", "rt_last_error",
+           "rt_multi_create", "rt_multi_set_camera", "rt_multi_set_views", "rt_multi_render", "rt_multi_last_ray_counts",
+           "rt_multi_last_render_ms", "rt_multi_destroy"]
 # every function include/rt_host.h declares
 HOST_EXPORTS = ["rt_host_scene_parse", "rt_host_scene_load", "rt_host_scene_desc", "rt_host_scene_camera",
                 "rt_host_scene_resize_screen", "rt_host_scene_turn_camera", "rt_host_scene_set_camera_pose",
@@ -84,6 +86,14 @@ def lib():
         L.rt_debug_set_queue_capacity.argtypes = [vp, u32]
         L.rt_debug_last_regrown.argtypes = [vp, C.POINTER(u32)]
         L.rt_last_error.restype = C.c_char_p
+        L.rt_multi_create.argtypes = [C.POINTER(abi.RtSceneDesc), C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+        L.rt_multi_set_camera.argtypes = [vp, C.POINTER(C.c_float), u32, u32]
+        L.rt_multi_set_views.argtypes = [vp, C.POINTER(C.c_float), u32, u32, u32]
+        L.rt_multi_render.argtypes = [vp, C.POINTER(abi.RtRenderParams), vp]
+        L.rt_multi_last_ray_counts.argtypes = [vp, C.POINTER(C.c_uint64)]
+        L.rt_multi_last_render_ms.argtypes = [vp, C.POINTER(C.c_float)]
+        L.rt_multi_destroy.argtypes = [vp]
+        L.rt_multi_destroy.restype = None
         fp = C.POINTER(C.c_float)
         L.rt_host_scene_parse.argtypes = [C.c_char_p, C.c_size_t, MESH_LOAD_FN, vp, C.POINTER(vp)]
         L.rt_host_scene_load.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(vp)]
@@ -220,6 +230,48 @@ class DeviceScene:
         n = C.c_uint32()
         check(lib().rt_debug_last_regrown(self._h, C.byref(n)))
         return int(n.value)
+
+
+class MultiDeviceScene:
+    """Owner of one RtMulti: the scene replicated on several GPUs of this process, frames tile-sharded over them
+    (rt_multi_* of include/rt_hip.h)."""
+
+    def __init__(self, desc: abi.RtSceneDesc, device_ids):
+        ids = (C.c_int * len(device_ids))(*device_ids)
+        self._h = C.c_void_p()
+        check(lib().rt_multi_create(C.byref(desc), ids, len(device_ids), C.byref(self._h)))
+        self.width = self.height = 0
+        self.n_views = 1
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rt_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_views(self, screen_to_world, width: int, height: int):
+        m = np.ascontiguousarray(np.asarray(screen_to_world, dtype=np.float32).reshape(-1, 16))
+        check(lib().rt_multi_set_views(self._h, m.ctypes.data_as(C.POINTER(C.c_float)), m.shape[0], width, height))
+        self.width, self.height, self.n_views = width, height, m.shape[0]
+
+    def set_camera(self, screen_to_world, width: int, height: int):
+        self.set_views(np.asarray(screen_to_world, dtype=np.float32).reshape(1, 16), width, height)
+
+    def render(self, max_depth: int = 10, channels: int = 3):
+        lead = (self.n_views,) if self.n_views > 1 else ()
+        rgb = np.zeros(lead + (self.height, self.width, channels), dtype=np.uint8)
+        p = abi.RtRenderParams(max_depth, abi.RT_FORMAT_RGBA8 if channels == 4 else abi.RT_FORMAT_RGB8, 0, 0, 0, 0, None)
+        check(lib().rt_multi_render(self._h, C.byref(p), rgb.ctypes.data_as(C.c_void_p)))
+        c = (C.c_uint64 * abi.RT_N_COUNTERS)()
+        check(lib().rt_multi_last_ray_counts(self._h, c))
+        ms = C.c_float()
+        check(lib().rt_multi_last_render_ms(self._h, C.byref(ms)))
+        return {"rgb": rgb, "counters": np.array(c, dtype=np.uint64), "ms": float(ms.value)}
 
 
 def write_png(path: str, pixels: np.ndarray):

@@ -81,6 +81,37 @@ def test_headline_workload_at_full_size(scenes_dir, tmp_path_factory):
     assert exact >= 0.9999
 
 
+def test_reference_render_bunny_free_pixels(scenes_dir):
+    """The device path against the reference's own picture: scenes/reflective_bunnies.json without its meshes at
+    3840x2160 against every pixel of render.png that no bunny can influence (tests/golden/reference_render_bunny_free.png,
+    made by tests/golden_mask.py) - planes, the triangle, the four spheres with refraction and Fresnel weights, shadows,
+    ten levels of recursion.  The matrices here come from the library's own transform code, not from nalgebra, hence
+    the usual colour bar instead of byte equality."""
+    from PIL import Image
+    golden = np.array(Image.open(os.path.join(os.path.dirname(__file__), "golden", "reference_render_bunny_free.png")).convert("RGBA"))
+    usable = golden[..., 3] == 255
+    scene = json.load(open(os.path.join(scenes_dir, "reflective_bunnies.json")))
+    scene["meshes"], scene["mesh_instances"] = [], []
+    host = native.HostScene.parse(json.dumps(scene))
+    m, w, h = host.camera()
+    assert (w, h) == (3840, 2160)
+    dev = native.DeviceScene(host.desc(), 0)
+    try:
+        dev.set_camera(m, w, h)
+        got = dev.render(max_depth=10)["rgb"]
+    finally:
+        dev.close()
+        host.close()
+    all_diff = np.abs(got.astype(int) - golden[..., :3].astype(int)).max(axis=2)
+    diff = all_diff[usable]
+    assert usable.sum() > 2_300_000
+    assert (diff <= 1).mean() >= 0.999, (diff <= 1).mean()
+    assert (diff == 0).mean() >= 0.99, (diff == 0).mean()
+    # the glass spheres (alpha 128: bunnies show through part of them): most of their pixels still agree
+    glass = all_diff[golden[..., 3] == 128]
+    assert glass.size > 500_000 and (glass <= 1).mean() >= 0.6, (glass <= 1).mean()
+
+
 @pytest.mark.parametrize("grid,n_meshes,level,width,height", [(4, 4, 3, 480, 270), (7, 5, 2, 320, 180)])
 def test_instance_grid(tmp_path_factory, grid, n_meshes, level, width, height):
     """Many instances over several distinct meshes, arbitrary rotations and non-uniform scales, two lights,
@@ -446,6 +477,64 @@ def test_native_app_writes_the_same_picture(scenes_dir, model_dir, tmp_path):
     finally:
         dev.close()
         host.close()
+
+
+def test_multi_device_renderer(scenes_dir, model_dir, tmp_path):
+    """rt_multi_*: one process, the scene replicated per device, tiles dealt round-robin, one exchange, stitched on the
+    first device.  A one-GPU box can run the RCCL path with a single device (ncclCommInitAll + ncclAllGather over one
+    rank) and the several-shard schedule with every shard on device 0; both must give rt_render's bytes and ray counts."""
+    import subprocess
+    from PIL import Image
+    from rust_raytracer_amd import synthetic
+    path = os.path.join(scenes_dir, "reflective_bunnies.json")
+    host = native.HostScene.load(path, model_dir)
+    host.resize_screen(333, 245)
+    m, w, h = host.camera()
+    dev = native.DeviceScene(host.desc(), 0)
+    try:
+        dev.set_camera(m, w, h)
+        want = dev.render(max_depth=7)
+        mats = []
+        for position, orientation in synthetic.orbit_poses(3, centre=(0.0, 0.0, -6.0)):
+            host.set_camera_pose(position, orientation)
+            mats.append(np.asarray(host.camera()[0], dtype=np.float32).reshape(16))
+        dev.set_views(np.stack(mats), w, h)
+        want_views = dev.render(max_depth=7)
+        for ids in ([0], [0, 0], [0, 0, 0, 0, 0]):
+            multi = native.MultiDeviceScene(host.desc(), ids)
+            try:
+                multi.set_camera(m, w, h)
+                got = multi.render(max_depth=7)
+                assert np.array_equal(got["rgb"], want["rgb"]), ids
+                assert got["counters"][:5].tolist() == want["counters"][:5].tolist()
+                assert got["ms"] > 0.0
+                rgba = multi.render(max_depth=7, channels=4)["rgb"]
+                assert np.array_equal(rgba[..., :3], want["rgb"]) and (rgba[..., 3] == 255).all()
+                multi.set_views(np.stack(mats), w, h)
+                got = multi.render(max_depth=7)
+                assert np.array_equal(got["rgb"], want_views["rgb"]), ids
+                assert got["counters"][:5].tolist() == want_views["counters"][:5].tolist()
+            finally:
+                multi.close()
+        with pytest.raises(native.RtError):
+            native.MultiDeviceScene(host.desc(), [0, 99])                 # no such device
+    finally:
+        dev.close()
+        host.close()
+    # the C++ front end: native_app --gpus 1 (RCCL, one rank) and --rehearse-gpus 3 write the picture native_app writes
+    app = os.path.join(os.path.dirname(scenes_dir), "rust_raytracer_amd", "native_app")
+    scene = json.load(open(path))
+    scene["camera"]["screen_dimensions"] = [300, 170]
+    small = str(tmp_path / "small.json")
+    json.dump(scene, open(small, "w"))
+    pictures = []
+    for extra in ([], ["--gpus", "1"], ["--rehearse-gpus", "3"]):
+        out = str(tmp_path / ("render%d.png" % len(pictures)))
+        r = subprocess.run([app] + extra + [small, model_dir, out, "6", "2"], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        pictures.append([np.asarray(Image.open(out))] + [np.asarray(Image.open("%s.%d.png" % (out, k))) for k in range(2)])
+    for other in pictures[1:]:
+        assert all(np.array_equal(a, b) for a, b in zip(pictures[0], other))
 
 
 def test_api_errors(scenes_dir, model_dir):

@@ -40,7 +40,8 @@ def test_noalloc_matches_render_device(scenes_dir, model_dir):
             got_counts = handle.last_ray_counts()             # also raises if a list of the scratch frame overflowed
             torch.cuda.synchronize()
             assert torch.equal(got, want), (w, h, shards)
-            assert got_counts.tolist() == want_counts.tolist() and got_counts[0] > w * h // shards
+            # (the walk's own work counters depend on how its lanes happened to share subtrees: only the ray counts are compared)
+            assert got_counts[:5].tolist() == want_counts[:5].tolist() and got_counts[0] > w * h // shards
             assert want.any()
         # a frame whose buffers do not fit the array: refused, with both sizes in the message, nothing rendered
         host.resize_screen(1920, 1080)

@@ -2,7 +2,10 @@
 // two durations - with paint_scene (main.rs:46-66) replaced by rt::HipRenderer.  The reference's three paths are
 // constants (main.rs:17-23); here they are arguments with the same defaults.
 //
-//     native_app [scene.json [model_dir [image.png [max_depth [n_orbit]]]]]
+//     native_app [--gpus N | --rehearse-gpus N] [scene.json [model_dir [image.png [max_depth [n_orbit]]]]]
+//
+// --gpus N renders every frame on the devices 0 .. N-1 of this machine (tiles dealt round-robin, stitched on device 0,
+// include/rt_hip.h rt_multi_*); --rehearse-gpus N runs the same schedule with N shards on device 0 alone.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -12,6 +15,15 @@
 #include "../include/rt_renderer.hpp"
 
 int main(int argc, char** argv) {
+    std::vector<int> devices;
+    if (argc > 2 && (std::string(argv[1]) == "--gpus" || std::string(argv[1]) == "--rehearse-gpus")) {
+        const bool rehearse = std::string(argv[1]) == "--rehearse-gpus";
+        const int n = std::atoi(argv[2]);
+        if (n < 1) { std::fprintf(stderr, "native_app: %s needs a positive count\n", argv[1]); return 2; }
+        for (int i = 0; i < n; ++i) devices.push_back(rehearse ? 0 : i);
+        argc -= 2;
+        argv += 2;
+    }
     const std::string scene_path = argc > 1 ? argv[1] : "res/scenes/og_scene_rust.json";
     const std::string model_dir = argc > 2 ? argv[2] : "res/models";
     const std::string image_path = argc > 3 ? argv[3] : "render.png";
@@ -19,7 +31,8 @@ int main(int argc, char** argv) {
     using clock = std::chrono::steady_clock;
     try {
         auto t0 = clock::now();
-        rt::HipRenderer renderer(0, 0, scene_path, model_dir);              // the scene file's own screen_dimensions
+        // the scene file's own screen_dimensions
+        rt::HipRenderer renderer = devices.empty() ? rt::HipRenderer(0, 0, scene_path, model_dir) : rt::HipRenderer(0, 0, scene_path, model_dir, devices);
         renderer.set_max_depth(max_depth);
         std::printf("Parsing took %.3fs\n", std::chrono::duration<float>(clock::now() - t0).count());
 
@@ -27,7 +40,8 @@ int main(int argc, char** argv) {
         t0 = clock::now();
         renderer.render_rgb(canvas.data(), canvas.size());
         std::printf("Rendering took %.3fs\n", std::chrono::duration<float>(clock::now() - t0).count());
-        std::printf("%llu rays, %.3f ms on the device\n", (unsigned long long)renderer.last_rays(), renderer.last_render_ms());
+        std::printf("%llu rays, %.3f ms on %s\n", (unsigned long long)renderer.last_rays(), renderer.last_render_ms(),
+                    devices.empty() ? "the device" : (std::to_string(devices.size()) + " devices, exchange and copy included").c_str());
 
         rt::check(rt_host_write_png(image_path.c_str(), canvas.data(), renderer.width(), renderer.height(), 3));
 
