@@ -195,6 +195,7 @@ typedef struct RtAux {              /* with several views (rt_scene_set_views): 
     uint32_t* instance_id;    /* W*H or NULL */
     uint8_t* flags;           /* W*H or NULL */
     uint64_t counters[RT_N_COUNTERS];   /* the device path fills RT_CTR_RAYS..RT_CTR_TRANSMITTED and RT_CTR_WALK_*, the rest stay 0 */
+    float* hit_t;             /* W*H or NULL: Hitpoint::t of the primary hit (hitpoint.rs:5), NaN where there is none */
 } RtAux;
 
 enum { RT_FORMAT_RGB8 = 0, RT_FORMAT_RGBA8 = 1 };

@@ -49,7 +49,7 @@ def lib():
         L.orc_scene_camera.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
         L.orc_scene_desc.argtypes = [C.c_void_p, C.POINTER(abi.RtSceneDesc)]
         L.orc_render.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_int,
-                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_trace_pixel.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_uint32, C.POINTER(C.c_float),
                                       C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)]
         fp = C.POINTER(C.c_float)
@@ -129,8 +129,8 @@ class OracleScene:
         return d
 
     def render(self, max_depth: int = 10, threads: int = 0, rows=None, channels: int = 3, aux: bool = True):
-        """Returns dict(rgb[H,W,channels] u8, prim_id[H,W] u32, instance_id[H,W] u32, flags[H,W] u8,
-        counters[RT_N_COUNTERS] u64).  Rows outside `rows` stay zero."""
+        """Returns dict(rgb[H,W,channels] u8, prim_id[H,W] u32, instance_id[H,W] u32, flags[H,W] u8, hit_t[H,W] f32
+        (Hitpoint::t of the primary hit, NaN without one), counters[RT_N_COUNTERS] u64).  Rows outside `rows` stay zero."""
         _, w, h = self.camera()
         threads = threads or (os.cpu_count() or 1)
         r0, r1 = rows if rows is not None else (0, h)
@@ -138,13 +138,14 @@ class OracleScene:
         prim = np.full((h, w), 0, dtype=np.uint32) if aux else None
         inst = np.full((h, w), 0, dtype=np.uint32) if aux else None
         flags = np.zeros((h, w), dtype=np.uint8) if aux else None
+        hit_t = np.zeros((h, w), dtype=np.float32) if aux else None
         ctr = np.zeros(abi.RT_N_COUNTERS, dtype=np.uint64)
         ptr = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
         rc = lib().orc_render(self._h, max_depth, threads, r0, r1, channels, ptr(rgb), ptr(prim), ptr(inst),
-                              ptr(flags), ptr(ctr))
+                              ptr(flags), ptr(hit_t), ptr(ctr))
         if rc != 0:
             raise RuntimeError("oracle: " + lib().orc_last_error().decode())
-        return {"rgb": rgb, "prim_id": prim, "instance_id": inst, "flags": flags, "counters": ctr}
+        return {"rgb": rgb, "prim_id": prim, "instance_id": inst, "flags": flags, "hit_t": hit_t, "counters": ctr}
 
     def render_depth_map(self, threads: int = 0, channels: int = 3):
         """Raytracer::depth_map for every pixel (raytracer.rs:21-28): dict(rgb, counters)."""

@@ -97,10 +97,10 @@ void orc_scene_desc(void* h, RtSceneDesc* d) {
 }
 
 int orc_render(void* h, uint32_t max_depth, int threads, uint32_t row_begin, uint32_t row_end, int channels,
-               uint8_t* rgb, uint32_t* prim_id, uint32_t* instance_id, uint8_t* flags, uint64_t* counters) {
+               uint8_t* rgb, uint32_t* prim_id, uint32_t* instance_id, uint8_t* flags, float* hit_t, uint64_t* counters) {
     try {
         render_frame(*static_cast<Scene*>(h), max_depth, threads, row_begin, row_end, channels, rgb, prim_id,
-                     instance_id, flags, counters);
+                     instance_id, flags, hit_t, counters);
         return 0;
     } catch (const std::exception& e) {
         g_error = e.what();

@@ -7,6 +7,7 @@
 // included.  Build with -ffp-contract=off, no -ffast-math.
 #include "orc_render.h"
 
+#include <limits>
 #include <atomic>
 #include <cstring>
 #include <stdexcept>
@@ -475,6 +476,7 @@ PixelResult trace_pixel(const Scene& s, float x, float y, uint32_t max_depth, Co
         r.instance_id = primary.instance_id;
     }
     r.flags = flags;
+    r.t = hit_recorded ? primary.t : std::numeric_limits<float>::quiet_NaN();
     return r;
 }
 
@@ -519,7 +521,7 @@ void render_depth_map(const Scene& s, int threads, int channels, uint8_t* rgb, u
 
 // native_app/src/main.rs:46-66 + canvas.rs:35-46 (canvas row r shows screen y = H-1-r)
 void render_frame(const Scene& s, uint32_t max_depth, int threads, uint32_t row_begin, uint32_t row_end, int channels,
-                  uint8_t* rgb, uint32_t* prim_id, uint32_t* instance_id, uint8_t* flags,
+                  uint8_t* rgb, uint32_t* prim_id, uint32_t* instance_id, uint8_t* flags, float* hit_t,
                   uint64_t counters[RT_N_COUNTERS]) {
     uint32_t W = s.camera.width, H = s.camera.height;
     if (row_end > H) row_end = H;
@@ -542,6 +544,7 @@ void render_frame(const Scene& s, uint32_t max_depth, int threads, uint32_t row_
                 if (prim_id) prim_id[idx] = pr.prim_id;
                 if (instance_id) instance_id[idx] = pr.instance_id;
                 if (flags) flags[idx] = pr.flags;
+                if (hit_t) hit_t[idx] = pr.t;
             }
         }
     };

@@ -42,6 +42,7 @@ struct PixelResult {
     Vec3 color;           // before quantisation
     uint32_t prim_id, instance_id;
     uint8_t flags;
+    float t;              // Hitpoint::t of the primary hit, NaN without one
 };
 
 // raytracer.rs:30-51
@@ -56,7 +57,7 @@ void quantize(Vec3 c, uint8_t out[3]);
 // may be null.  rgb has `channels` (3 or 4) bytes per pixel; alpha = 255
 // (web_app/wasm/src/color.rs:10-21).
 void render_frame(const Scene& s, uint32_t max_depth, int threads, uint32_t row_begin, uint32_t row_end,
-                  int channels, uint8_t* rgb, uint32_t* prim_id, uint32_t* instance_id, uint8_t* flags,
+                  int channels, uint8_t* rgb, uint32_t* prim_id, uint32_t* instance_id, uint8_t* flags, float* hit_t,
                   uint64_t counters[RT_N_COUNTERS]);
 
 }  // namespace orc

@@ -89,7 +89,7 @@ class RtSceneDesc(C.Structure):
 
 class RtAux(C.Structure):
     _fields_ = [("prim_id", C.POINTER(u32)), ("instance_id", C.POINTER(u32)), ("flags", C.POINTER(C.c_uint8)),
-                ("counters", C.c_uint64 * RT_N_COUNTERS)]
+                ("counters", C.c_uint64 * RT_N_COUNTERS), ("hit_t", C.POINTER(f32))]
 
 
 class RtRenderParams(C.Structure):

@@ -21,7 +21,7 @@ hipError_t rt_launch_generate(const DFrame* F, const DViews* V, uint32_t blocks,
 hipError_t rt_launch_level(const DScene* S, const DFrame* F, uint32_t level, uint32_t blocks, uint32_t traverse_blocks,
                            hipStream_t stream, hipEvent_t* marks);
 hipError_t rt_launch_resolve(const DFrame* F, uint8_t* out, uint32_t bytes_per_pixel, uint32_t tiled, hipStream_t stream);
-hipError_t rt_launch_resolve_aux(const DFrame* F, uint32_t* prim, uint32_t* inst, uint8_t* flags, hipStream_t stream);
+hipError_t rt_launch_resolve_aux(const DFrame* F, uint32_t* prim, uint32_t* inst, uint8_t* flags, float* hit_t, hipStream_t stream);
 hipError_t rt_launch_assemble(const uint8_t* gathered, uint8_t* frame, uint32_t width, uint32_t height, uint32_t tiles_x,
                               uint32_t shard_count, uint32_t tiles_per_shard, uint32_t bytes_per_pixel, uint32_t n_views,
                               hipStream_t stream);
@@ -85,6 +85,7 @@ struct RtScene {
     size_t d_pixels_bytes = 0;
     uint32_t *d_aux_prim_out = nullptr, *d_aux_inst_out = nullptr;
     uint8_t* d_aux_flags_out = nullptr;
+    float* d_aux_t_out = nullptr;
     size_t aux_out_pixels = 0;
     uint32_t debug_queue_capacity = 0;
     size_t stats_words = 0;
@@ -536,6 +537,7 @@ extern "C" void rt_scene_destroy(RtScene* s) {
     if (s->d_aux_prim_out) (void)hipFree(s->d_aux_prim_out);
     if (s->d_aux_inst_out) (void)hipFree(s->d_aux_inst_out);
     if (s->d_aux_flags_out) (void)hipFree(s->d_aux_flags_out);
+    if (s->d_aux_t_out) (void)hipFree(s->d_aux_t_out);
     if (s->h_overflow) (void)hipHostFree(const_cast<unsigned int*>(s->h_overflow));
     for (hipEvent_t e : s->marks) (void)hipEventDestroy(e);
     if (s->ev_start) (void)hipEventDestroy(s->ev_start);
@@ -645,7 +647,7 @@ static int carve_frame(uint32_t n_pixels, uint32_t n_lights, uint32_t blocks, ui
     f.slow_flags = c; c += RT_MAX_DEPTH_LIMIT + 2;
     f.wave_stats = c;
     if (aux && ((rc = get((size_t)n_pixels, &f.aux_flags)) || (rc = get((size_t)n_pixels, &f.aux_prim)) ||
-                (rc = get((size_t)n_pixels, &f.aux_inst))))
+                (rc = get((size_t)n_pixels, &f.aux_inst)) || (rc = get((size_t)n_pixels, &f.aux_t))))
         return rc;
     return RT_OK;
 }
@@ -792,7 +794,7 @@ static int enqueue_frame(RtScene* s, const RtRenderParams* p, bool sharded, bool
     f.mode = p->mode;
     if (++s->frame_seq == 0) s->frame_seq = 1;
     f.overflow_seq = s->frame_seq;
-    if (!aux) f.aux_flags = f.aux_prim = f.aux_inst = nullptr;
+    if (!aux) { f.aux_flags = f.aux_prim = f.aux_inst = nullptr; f.aux_t = nullptr; }
     HIP_TRY(hipEventRecord(s->ev_start, stream));
     HIP_TRY(hipMemsetAsync(f.acc, 0, sz.pixel_clear_bytes, stream));                              // colour sums + poison words
     HIP_TRY(hipMemsetAsync(f.ray_counts[0], 0, sz.counter_words * sizeof(unsigned int), stream));  // every counter + statistics
@@ -862,7 +864,7 @@ extern "C" int rt_render(RtScene* s, const RtRenderParams* p, uint8_t* out_pixel
         HIP_TRY(hipMalloc((void**)&s->d_pixels, bytes));
         s->d_pixels_bytes = bytes;
     }
-    bool want_aux = aux && (aux->prim_id || aux->instance_id || aux->flags);
+    bool want_aux = aux && (aux->prim_id || aux->instance_id || aux->flags || aux->hit_t);
     s->regrown = 0;
     note_overflow(s);
     const bool owed = s->overflow_unreported;      // an overflow of an earlier rt_render_device frame, still to be reported
@@ -875,17 +877,20 @@ extern "C" int rt_render(RtScene* s, const RtRenderParams* p, uint8_t* out_pixel
                 if (s->d_aux_prim_out) (void)hipFree(s->d_aux_prim_out);
                 if (s->d_aux_inst_out) (void)hipFree(s->d_aux_inst_out);
                 if (s->d_aux_flags_out) (void)hipFree(s->d_aux_flags_out);
-                s->d_aux_prim_out = s->d_aux_inst_out = nullptr; s->d_aux_flags_out = nullptr; s->aux_out_pixels = 0;
+                if (s->d_aux_t_out) (void)hipFree(s->d_aux_t_out);
+                s->d_aux_prim_out = s->d_aux_inst_out = nullptr; s->d_aux_flags_out = nullptr; s->d_aux_t_out = nullptr; s->aux_out_pixels = 0;
                 HIP_TRY(hipMalloc((void**)&s->d_aux_prim_out, n * 4));
                 HIP_TRY(hipMalloc((void**)&s->d_aux_inst_out, n * 4));
                 HIP_TRY(hipMalloc((void**)&s->d_aux_flags_out, n));
+                HIP_TRY(hipMalloc((void**)&s->d_aux_t_out, n * 4));
                 s->aux_out_pixels = n;
             }
             DFrame f = s->last_f;
-            HIP_TRY(rt_launch_resolve_aux(&f, s->d_aux_prim_out, s->d_aux_inst_out, s->d_aux_flags_out, stream));
+            HIP_TRY(rt_launch_resolve_aux(&f, s->d_aux_prim_out, s->d_aux_inst_out, s->d_aux_flags_out, s->d_aux_t_out, stream));
             if (aux->prim_id) HIP_TRY(hipMemcpyAsync(aux->prim_id, s->d_aux_prim_out, n * 4, hipMemcpyDeviceToHost, stream));
             if (aux->instance_id) HIP_TRY(hipMemcpyAsync(aux->instance_id, s->d_aux_inst_out, n * 4, hipMemcpyDeviceToHost, stream));
             if (aux->flags) HIP_TRY(hipMemcpyAsync(aux->flags, s->d_aux_flags_out, n, hipMemcpyDeviceToHost, stream));
+            if (aux->hit_t) HIP_TRY(hipMemcpyAsync(aux->hit_t, s->d_aux_t_out, n * 4, hipMemcpyDeviceToHost, stream));
         }
         HIP_TRY(hipMemcpyAsync(out_pixels, s->d_pixels, bytes, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));

@@ -150,6 +150,7 @@ struct DFrame {
     unsigned int* aux_flags;         // [n_pixels] or null
     unsigned int* aux_prim;          // [n_pixels] or null
     unsigned int* aux_inst;          // [n_pixels] or null
+    float* aux_t;                    // [n_pixels] or null: t of the primary hit
     // Ray records of the current / next depth, 2 float4 each.  Slots below shadow_base form the segmented list
     // of the primary / reflected / transmitted rays; the shadow ray of hit record h towards light l has the fixed
     // slot shadow_base + h * n_lights + l (raytracer.rs:77-79: one per light per Phong-shaded hit), so the shadow

@@ -1574,6 +1574,7 @@ __global__ void __launch_bounds__(RT_SHADE_THREADS) rt_shade(const DScene S, con
                     if (level == 0) {
                         F.aux_prim[pixel] = cl.prim;
                         F.aux_inst[pixel] = cl.inst;
+                        F.aux_t[pixel] = best_t;
                         atomicOr(F.aux_flags + pixel, RT_FLAG_HIT | (hit.on_frontside ? RT_FLAG_FRONTSIDE : 0u));
                     } else if (level == 1 && returns_some) {
                         atomicOr(F.aux_flags + pixel, kind ? RT_FLAG_REFRACTION_HIT : RT_FLAG_REFLECTION_HIT);
@@ -1711,7 +1712,7 @@ __global__ void rt_resolve(const DFrame F, uint8_t* out, uint32_t bytes_per_pixe
 }
 
 // Scatters the aux planes (local pixel order) into row-major W*H arrays.
-__global__ void rt_resolve_aux(const DFrame F, uint32_t* prim, uint32_t* inst, uint8_t* flags) {
+__global__ void rt_resolve_aux(const DFrame F, uint32_t* prim, uint32_t* inst, uint8_t* flags, float* hit_t) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= F.n_pixels) return;
     uint32_t view, col, row;
@@ -1722,6 +1723,7 @@ __global__ void rt_resolve_aux(const DFrame F, uint32_t* prim, uint32_t* inst, u
     if (prim) prim[at] = hit ? F.aux_prim[p] : RT_PRIM_NONE;
     if (inst) inst[at] = hit ? F.aux_inst[p] : RT_INSTANCE_NONE;
     if (flags) flags[at] = (uint8_t)fl;
+    if (hit_t) hit_t[at] = hit ? F.aux_t[p] : __uint_as_float(0x7FC00000u);
 }
 
 // Gathered shard buffers (rank-major; inside a rank view-major, then tile-major) -> row-major frames, view after view.
@@ -1806,10 +1808,10 @@ extern "C" hipError_t rt_launch_resolve(const DFrame* F, uint8_t* out, uint32_t 
     return hipGetLastError();
 }
 
-extern "C" hipError_t rt_launch_resolve_aux(const DFrame* F, uint32_t* prim, uint32_t* inst, uint8_t* flags,
+extern "C" hipError_t rt_launch_resolve_aux(const DFrame* F, uint32_t* prim, uint32_t* inst, uint8_t* flags, float* hit_t,
                                             hipStream_t stream) {
     uint32_t blocks = (F->n_pixels + 255) / 256;
-    hipLaunchKernelGGL(rt_resolve_aux, dim3(blocks), dim3(256), 0, stream, *F, prim, inst, flags);
+    hipLaunchKernelGGL(rt_resolve_aux, dim3(blocks), dim3(256), 0, stream, *F, prim, inst, flags, hit_t);
     return hipGetLastError();
 }
 

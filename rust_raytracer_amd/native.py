@@ -155,7 +155,7 @@ class DeviceScene:
         return abi.RtRenderParams(max_depth, fmt, shard_index, shard_count, mode, 0, stream)
 
     def render(self, max_depth: int = 10, channels: int = 3, aux: bool = False, depth_map: bool = False):
-        """Whole frame to host memory: dict(rgb[H,W,channels], counters, and with aux prim_id / instance_id / flags);
+        """Whole frame to host memory: dict(rgb[H,W,channels], counters, and with aux prim_id / instance_id / flags / hit_t);
         after set_views every array has a leading view axis."""
         h, w = self.height, self.width
         lead = (self.n_views,) if self.n_views > 1 else ()
@@ -168,6 +168,8 @@ class DeviceScene:
             out["prim_id"] = np.zeros(lead + (h, w), dtype=np.uint32)
             out["instance_id"] = np.zeros(lead + (h, w), dtype=np.uint32)
             out["flags"] = np.zeros(lead + (h, w), dtype=np.uint8)
+            out["hit_t"] = np.zeros(lead + (h, w), dtype=np.float32)
+            a.hit_t = out["hit_t"].ctypes.data_as(C.POINTER(C.c_float))
             a.prim_id = out["prim_id"].ctypes.data_as(C.POINTER(C.c_uint32))
             a.instance_id = out["instance_id"].ctypes.data_as(C.POINTER(C.c_uint32))
             a.flags = out["flags"].ctypes.data_as(C.POINTER(C.c_uint8))

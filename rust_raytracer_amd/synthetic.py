@@ -214,3 +214,79 @@ def spoiled_scene(model_dir: str, seed: int, width: int = 96, height: int = 64):
         scene["lights"][0]["position"] = {"x": p["x"], "y": p["y"], "z": p["z"], "w": 1}
         done.append("light at the camera")
     return json.dumps(scene), done
+
+
+def pruning_stress_scene(model_dir: str, seed: int = 0):
+    """A scene built to sit on the edges of the BVH walk's distance pruning (the walk may only skip what cannot win):
+
+    * a lattice of axis-aligned squares (two triangles each, edge 0.35, so |e1||e2| = 0.1225 stays just inside the bound
+      of 0.125 up to which a mesh is walked with pruning): their boxes are flat, and rays parallel to an axis through
+      dyadic coordinates run exactly inside triangle planes and along box faces;
+    * slivers almost parallel to the view direction: Moeller-Trumbore's determinant for a ray along -z is between 1e-5
+      and 2e-5, just above the reference's rejection threshold (intersect.rs:152), where the computed t is least
+      accurate; several of them behind each other so that a wrongly pruned one would change the winner;
+    * point lights exactly on lattice vertices, so shadow rays end at the distance of a candidate (raytracer.rs:178-186).
+
+    Returns (scene JSON text, [(screen_to_world column-major 16 floats, width, height)] of parallel-ray cameras that
+    look along -z: one over the whole lattice on dyadic coordinates, one zoomed into the slivers)."""
+    import random
+    rng = random.Random(seed)
+    os.makedirs(model_dir, exist_ok=True)
+    v, f = [], []
+
+    def quad(p, a, b):
+        k = len(v)
+        v.extend([p, tuple(p[i] + a[i] for i in range(3)), tuple(p[i] + a[i] + b[i] for i in range(3)), tuple(p[i] + b[i] for i in range(3))])
+        f.extend([(k, k + 1, k + 2), (k, k + 2, k + 3)])
+
+    e = 0.35
+    for i in range(5):
+        for j in range(5):
+            for k in range(3):
+                p = (-0.875 + i * 0.375, -0.875 + j * 0.375, -4.0 - k * 0.375)
+                which = rng.randrange(3)
+                if which == 0: quad(p, (e, 0, 0), (0, e, 0))          # plane z = const: hit head-on
+                elif which == 1: quad(p, (e, 0, 0), (0, 0, -e))       # plane y = const: rays run inside it
+                else: quad(p, (0, e, 0), (0, 0, -e))                  # plane x = const
+    sliver_y = 1.25
+    for k in range(6):
+        s = (1.0 + 0.15 * k) * 1e-4                                   # determinant 0.1225 * s for a ray along -z
+        z0 = -2.0 - 0.36 * k
+        kk = len(v)
+        v.extend([(-0.175, sliver_y + 3e-6 * k, z0), (0.175, sliver_y + 3e-6 * k, z0), (-0.175, sliver_y + 3e-6 * k + e * s, z0 - e)])
+        f.append((kk, kk + 1, kk + 2))
+    name = "pruning_stress_%d.obj" % seed
+    lines = ["o stress"] + ["v %.9g %.9g %.9g" % p for p in v] + ["vn 0 0 1"]
+    lines += ["f %d//1 %d//1 %d//1" % (a + 1, b + 1, c + 1) for a, b, c in f]
+    with open(os.path.join(model_dir, name), "w") as fh:
+        fh.write("\n".join(lines) + "\n")
+    scene = {
+        "camera": {"position": _xyz(0, 0, 0), "orientation_degrees": _xyz(0, 0, 0), "screen_dimensions": [64, 64], "y_fov_degrees": 60,
+                   "z_near": 0.1, "z_far": 60, "use_perspective": True, "ortho_world_height": 10},
+        "background": "ColoredDirection",
+        "lights": [{"position": {"x": -0.875 + 0.375 * a, "y": -0.875 + 0.375 * b, "z": -4.0 - 0.375 * c, "w": 1},
+                    "color": {"ambient": _rgb(0.2, 0.2, 0.2), "diffuse": _rgb(0.5, 0.5, 0.5), "specular": _rgb(0.3, 0.3, 0.3)}}
+                   for a, b, c in [(1, 2, 0), (3, 1, 1)]],
+        "materials": [{"name": "matte", "emissive": _rgb(0.05, 0.02, 0.02), "ambient": _rgb(0.3, 0.3, 0.4), "diffuse": _rgb(0.5, 0.6, 0.7),
+                       "specular": _rgb(0.4, 0.4, 0.4), "shininess": 9, "material_type": "Phong"},
+                      {"name": "mirror", "emissive": _rgb(0, 0, 0), "ambient": _rgb(0.1, 0.1, 0.1), "diffuse": _rgb(0.2, 0.2, 0.2),
+                       "specular": _rgb(0.7, 0.7, 0.7), "shininess": 30, "material_type": "ReflectAndPhong"}],
+        "planes": [{"normal": _xyz(0, 0, 1), "distance": -6.0, "material": "matte"}],
+        "spheres": [], "triangles": [],
+        "meshes": [{"name": "stress", "file_name": name, "winding_order": "CounterClockwise", "material": "matte"}],
+        "mesh_instances": [{"mesh": "stress", "position": _xyz(0, 0, 0), "orientation_degrees": _xyz(0, 0, 0), "scale": _xyz(1, 1, 1)},
+                           {"mesh": "stress", "position": _xyz(0.375, 0, -1.5), "orientation_degrees": _xyz(0, 0, 0), "scale": _xyz(1, 1, 1),
+                            "material_override": "mirror"}],
+    }
+
+    def parallel_camera(x0, y0, step, width, height, step_y=None):
+        # pixel (x, y) -> origin (x0 + x * step, y0 + y * step_y, 0), direction (0, 0, -1)  (raytracer.rs:30-51 with an affine matrix)
+        m = [0.0] * 16
+        m[0] = step; m[5] = step if step_y is None else step_y; m[10] = -1.0
+        m[12], m[13], m[14], m[15] = x0, y0, 0.0, 1.0
+        return m, width, height
+
+    cameras = [parallel_camera(-1.0, -1.0, 1.0 / 64.0, 160, 160),                       # dyadic coordinates: rays inside planes and box faces
+               parallel_camera(-0.2, sliver_y - 8.0 / 1048576.0, 1.0 / 256.0, 96, 96, 1.0 / 1048576.0),  # 2^-20 per row across the slivers
+               parallel_camera(-0.99, -0.99, 0.0123, 170, 170)]                          # a generic lattice of rays
+    return json.dumps(scene), cameras

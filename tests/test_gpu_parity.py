@@ -37,6 +37,9 @@ def assert_parity(got, want, min_within_1=0.999):
     assert np.array_equal(got["flags"], want["flags"]), "flags differ on %d pixels" % (got["flags"] != want["flags"]).sum()
     assert np.array_equal(got["prim_id"], want["prim_id"]), "prim ids differ on %d pixels" % (got["prim_id"] != want["prim_id"]).sum()
     assert np.array_equal(got["instance_id"], want["instance_id"])
+    # Hitpoint::t of the primary hits, bit for bit (NaN where nothing is hit, and for the hits of NaN rays)
+    assert np.array_equal(got["hit_t"], want["hit_t"], equal_nan=True), "primary t differs on %d pixels" % (
+        ~((got["hit_t"] == want["hit_t"]) | (np.isnan(got["hit_t"]) & np.isnan(want["hit_t"])))).sum()
     assert got["counters"][:5].tolist() == want["counters"][:5].tolist()
     diff = np.abs(got["rgb"].astype(int) - want["rgb"].astype(int)).max(axis=2)
     within = (diff <= 1).mean()
@@ -48,6 +51,74 @@ def load(scenes_dir, model_dir, name, width, height):
     s = orc.OracleScene.from_file(os.path.join(scenes_dir, name + ".json"), model_dir)
     s.resize(width, height)
     return s
+
+
+def shoot(desc, origin, direction):
+    """One ray through the device path: a 1x1 frame whose screen_to_world matrix maps the pixel to `origin` and the
+    point one unit deeper to origin + direction (raytracer.rs:30-51).  Returns (prim_id, t) of Scene::intersect."""
+    m = np.zeros((4, 4), dtype=np.float32)         # column-major: m[c] is column c
+    m[2, :3] = direction
+    m[3, :3] = origin
+    m[3, 3] = 1.0
+    dev = native.DeviceScene(desc, 0)
+    try:
+        dev.set_camera(m.reshape(16), 1, 1)
+        r = dev.render(max_depth=1, aux=True)
+    finally:
+        dev.close()
+    hit = bool(r["flags"][0, 0] & abi.RT_FLAG_HIT)
+    assert np.isnan(r["hit_t"][0, 0]) != hit
+    return (int(r["prim_id"][0, 0]), float(r["hit_t"][0, 0])) if hit else None
+
+
+def test_reference_intersection_kats_on_the_device():
+    """The reference's own known-answer tests (lib_raytracer/src/raytracing/intersect_tests.rs:8-161) through the HIP
+    path: each case is a scene with the one primitive and a one-pixel frame whose ray is the test's ray; the hit
+    distance comes back through RtAux::hit_t and is held to the reference's tolerance (utils/mod.rs:4-7:
+    relative error <= 2 * f32::EPSILON).  tests/test_oracle_kat.py runs the same cases on the oracle."""
+    import ctypes as C
+    eps = float(np.finfo(np.float32).eps)
+
+    def scene_with(**arrays):
+        d = abi.RtSceneDesc()
+        d.background.type = abi.RT_BACKGROUND_COLORED_DIRECTION
+        keep = [(abi.RtMaterial * 1)()]
+        d.n_materials, d.materials = 1, C.cast(keep[0], C.POINTER(abi.RtMaterial))
+        for name, items in arrays.items():
+            arr = (type(items[0]) * len(items))(*items)
+            keep.append(arr)
+            setattr(d, "n_" + name, len(items))
+            setattr(d, name, C.cast(arr, C.POINTER(type(items[0]))))
+        return d, keep
+
+    def check(desc, origin, direction, expected, kind):
+        got = shoot(desc, origin, direction)
+        if expected is None:
+            assert got is None, (origin, direction, got)
+        else:
+            assert got is not None, (origin, direction)
+            assert got[0] == kind << 30 and abs(got[1] - expected) <= 2.0 * eps * max(abs(got[1]), abs(expected)), (origin, direction, got)
+
+    f3 = lambda v: (abi.f32 * 3)(*[float(x) for x in v])
+    sphere, keep1 = scene_with(spheres=[abi.RtSphere(f3((0, 0, 0)), 1.0, 0)])                          # intersect_tests.rs:8-19
+    for origin, direction, expected in [((0, 0, -4100.0), (0, 0, 1), 4099.0), ((0, 0, -2.0), (0, 1, 0), None),
+                                        ((0, 0, -2.0), (0, 0, 1), 1.0), ((0, 0, 0.0), (0, 0, 1), 1.0),
+                                        ((-1, 0, -1.0), (0, 0, 1), 1.0), ((0, 0, -1.1), (0, 0, -1), None)]:     # :20-90
+        check(sphere, origin, direction, expected, abi.RT_PRIM_SPHERE)
+    tri = abi.RtTriangle()                                                                              # :96-102
+    for k, v in enumerate([(-1, 1, 0), (1, 0, 0), (-1, -1, 0)]):
+        tri.vertices[k] = f3(v)
+    # Triangle::new's face normal: normalize(cross(c - a, b - a)), geometry/triangle.rs:43
+    a, b, c = (np.array(tri.vertices[k][:], dtype=np.float32) for k in range(3))
+    n = np.cross(c - a, b - a).astype(np.float32)
+    tri.face_normal = f3(n / np.sqrt((n * n).sum(dtype=np.float32)))
+    triangle, keep2 = scene_with(triangles=[tri])
+    for direction, expected in [((0, 0, 1), 2.0), ((0, 0, -1), None), ((0, 1, 0), None)]:                  # :104-127
+        check(triangle, (0, 0, -2.0), direction, expected, abi.RT_PRIM_TRIANGLE)
+    plane, keep3 = scene_with(planes=[abi.RtPlane(f3((0, 0, -1)), 1.0, 0)])                              # :133-136
+    for origin, direction, expected in [((0, 0, -2.0), (0, 1, 0), None), ((0, 0, -2.0), (0, 0, 1), 1.0),
+                                        ((0, 0, 0.0), (0, 0, 1), None)]:                                 # :138-160
+        check(plane, origin, direction, expected, abi.RT_PRIM_PLANE)
 
 
 @pytest.mark.parametrize("width,height", [(320, 180), (1280, 720)])
@@ -110,6 +181,59 @@ def test_reference_render_bunny_free_pixels(scenes_dir):
     # the glass spheres (alpha 128: bunnies show through part of them): most of their pixels still agree
     glass = all_diff[golden[..., 3] == 128]
     assert glass.size > 500_000 and (glass <= 1).mean() >= 0.6, (glass <= 1).mean()
+
+
+@pytest.mark.parametrize("name", ["mirror_sphere", "infinity_santa"])
+def test_depth16_scenes_at_full_size(scenes_dir, tmp_path_factory, name):
+    """The divergence and stack-depth configurations at their own size: 1920x1080, reflection depth 16, full-size stand-in
+    meshes (66 M and 73 M rays) - every pixel against the oracle."""
+    from rust_raytracer_amd import meshes
+    full_models = meshes.ensure_model_dir(str(tmp_path_factory.mktemp("full_models16")))
+    got, want = render_both(load(scenes_dir, full_models, name, 1920, 1080), max_depth=16)
+    exact, within = assert_parity(got, want)
+    print("%s 1920x1080 depth 16: %d rays, %.5f of the pixels identical, %.5f within 1 LSB" % (name, int(got["counters"][0]), exact, within))
+    assert got["counters"][0] > 60_000_000
+
+
+def test_instance_grid_2p6m_triangles_at_4k(tmp_path_factory):
+    """The many-mesh configuration at benchmark size: 64 instances over 32 distinct meshes of 81 920 triangles
+    (2.6 M triangles, far beyond the caches) at 3840x2160 - every pixel against the oracle."""
+    from rust_raytracer_amd import synthetic
+    d = str(tmp_path_factory.mktemp("grid_models_2p6m"))
+    s = orc.OracleScene.from_text(synthetic.instance_grid_scene(d, 8, 32, 6, 3840, 2160), d)
+    assert s.desc().n_mesh_triangles == 32 * 81920
+    got, want = render_both(s)
+    exact, within = assert_parity(got, want)
+    print("instance grid 2.6 M triangles 3840x2160: %d rays, %.5f identical, %.5f within 1 LSB" % (int(got["counters"][0]), exact, within))
+    assert (got["prim_id"] >> 30 == abi.RT_PRIM_MESH_TRIANGLE).sum() > 1_000_000
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_pruning_bound_adversarial(tmp_path_factory, seed):
+    """synthetic.pruning_stress_scene: a mesh that is walked with distance pruning (|e1||e2| = 0.1225, bound 0.125) seen
+    through parallel rays that run inside triangle planes and along box faces, slivers whose Moeller-Trumbore
+    determinant is 1e-5 .. 2e-5 stacked behind each other, point lights exactly at candidates' distances.  Whatever
+    the pruned, near-first walk skips must not change a winner, a shadow verdict or a t."""
+    from rust_raytracer_amd import synthetic
+    d = str(tmp_path_factory.mktemp("stress_models"))
+    text, cameras = synthetic.pruning_stress_scene(d, seed)
+    s = orc.OracleScene.from_text(text, d)
+    dev = native.DeviceScene(s.desc(), 0)
+    try:
+        sliver_hits = 0
+        for k, (m, w, h) in enumerate(cameras):
+            m = np.asarray(m, dtype=np.float32)
+            s.set_camera_matrix(m, w, h)
+            dev.set_camera(m, w, h)
+            got, want = dev.render(max_depth=6, aux=True), s.render(max_depth=6)
+            assert_parity(got, want)
+            mesh = got["prim_id"] >> 30 == abi.RT_PRIM_MESH_TRIANGLE
+            assert mesh.sum() > w * h // 8
+            if k == 1:
+                sliver_hits = len(np.unique(got["prim_id"][mesh]))
+        assert sliver_hits == 6                      # every sliver wins somewhere
+    finally:
+        dev.close()
 
 
 @pytest.mark.parametrize("grid,n_meshes,level,width,height", [(4, 4, 3, 480, 270), (7, 5, 2, 320, 180)])
@@ -404,13 +528,16 @@ def test_random_scenes(tmp_path_factory, block):
     Ids, flags and ray counts must agree exactly with the oracle, colours within the usual tolerance."""
     from rust_raytracer_amd import synthetic
     d = str(tmp_path_factory.mktemp("fuzz_models"))
+    worst = 1.0
     for seed in range(block * 12, block * 12 + 12):
         s = orc.OracleScene.from_text(synthetic.random_scene(d, seed), d)
         got, want = render_both(s, max_depth=6)
         try:
-            assert_parity(got, want, min_within_1=0.995)
+            # the generator keeps refraction off the meshes and free triangles, so the colour bar is the full one
+            worst = min(worst, assert_parity(got, want, min_within_1=0.999)[1])
         except AssertionError as e:
             raise AssertionError("seed %d: %s" % (seed, e))
+    print("random scenes %d..%d: worst share of pixels within 1 LSB %.5f" % (block * 12, block * 12 + 11, worst))
 
 
 @pytest.mark.parametrize("block", range(3))
@@ -421,14 +548,16 @@ def test_spoiled_random_scenes(tmp_path_factory, block):
     from rust_raytracer_amd import synthetic
     d = str(tmp_path_factory.mktemp("spoiled_models"))
     seen = set()
+    worst = 1.0
     for seed in range(block * 40, block * 40 + 40):
         text, what = synthetic.spoiled_scene(d, seed)
         seen.update(what)
         got, want = render_both(orc.OracleScene.from_text(text, d), max_depth=5)
         try:
-            assert_parity(got, want, min_within_1=0.99)
+            worst = min(worst, assert_parity(got, want, min_within_1=0.999)[1])
         except AssertionError as e:
             raise AssertionError("seed %d %s: %s" % (seed, what, e))
+    print("spoiled scenes %d..%d: worst share of pixels within 1 LSB %.5f" % (block * 40, block * 40 + 39, worst))
     assert {"duplicate instance", "zero scale", "duplicate sphere", "duplicate plane"} <= seen
 
 
