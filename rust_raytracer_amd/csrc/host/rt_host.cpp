@@ -9,6 +9,7 @@
 // are merged instead of re-scanned - min/max are exact, so the merge order does not matter).
 //
 // Compiled with -ffp-contract=off: float arithmetic below is plain IEEE binary32.
+#include <cctype>
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -355,25 +356,37 @@ struct ObjCursor {
         buf[n] = 0;
         return strtof(buf, nullptr);
     }
+    // An optionally signed decimal integer at p, never reading at or beyond `end` (the buffer need not be
+    // NUL-terminated) nor across white space (strtol would skip a line break and take the next line's number).
+    // Returns false, leaving p alone, when there is no digit.
+    bool integer(long& out) {
+        const char* q = p;
+        bool negative = false;
+        if (q < end && (*q == '-' || *q == '+')) { negative = *q == '-'; ++q; }
+        if (q >= end || *q < '0' || *q > '9') return false;
+        long v = 0;
+        while (q < end && *q >= '0' && *q <= '9') { if (v < (1L << 40)) v = v * 10 + (*q - '0'); ++q; }
+        out = negative ? -v : v;
+        p = q;
+        return true;
+    }
     // one "v", "v/vt", "v//vn" or "v/vt/vn" corner; returns false at end of line
     bool corner(long& v, long& vn, bool& has_vn) {
         skip_blank();
         if (at_eol()) return false;
-        char* q = nullptr;
-        v = strtol(p, &q, 10);
-        p = q;
+        if (!integer(v)) { v = 0; while (p < end && *p != ' ' && *p != '\t' && *p != '\r' && *p != '\n' && *p != '/') ++p; }   // strtol gives 0 for no digits
         has_vn = false;
         if (p < end && *p == '/') {
             ++p;
-            if (p < end && *p != '/') { (void)strtol(p, &q, 10); p = q; }
+            long vt;
+            (void)integer(vt);
             if (p < end && *p == '/') {
                 ++p;
-                const char* before = p;
-                vn = strtol(p, &q, 10);
-                p = q;
-                has_vn = p != before;
+                has_vn = integer(vn);
             }
         }
+        // whatever else clings to the corner is skipped, so that the caller sees the next corner or the end of the line
+        while (p < end && *p != ' ' && *p != '\t' && *p != '\r' && *p != '\n') ++p;
         return true;
     }
 };
@@ -512,10 +525,15 @@ struct Json {
         if (word("true")) { nodes[id].type = Bool; nodes[id].num = 1; return id; }
         if (word("false")) { nodes[id].type = Bool; return id; }
         if (word("null")) return id;
+        // a JSON number, copied out first: the text need not be NUL-terminated and strtod must not read beyond `end`
+        char buf[64];
+        size_t n = 0;
+        while (p + n < end && n + 1 < sizeof(buf) && (isdigit((unsigned char)p[n]) || p[n] == '-' || p[n] == '+' || p[n] == '.' || p[n] == 'e' || p[n] == 'E')) { buf[n] = p[n]; ++n; }
+        buf[n] = 0;
         char* q = nullptr;
-        double d = strtod(p, &q);
-        if (q == p) raise(RT_ERR_PARSE, "scene json: unexpected character");
-        p = q;
+        double d = strtod(buf, &q);
+        if (q == buf) raise(RT_ERR_PARSE, "scene json: unexpected character");
+        p += q - buf;
         nodes[id].type = Num;
         nodes[id].num = d;
         return id;

@@ -196,3 +196,20 @@ def test_reference_own_mesh_files():
     nodes = as_numeric(a["mesh_bvh_nodes"], abi.RtBvhNode)
     leaves = nodes["is_leaf"] != 0
     assert nodes["triangle_count"][leaves].sum() == 22200 and nodes["triangle_count"][leaves].max() <= 5
+
+
+def test_rust_shim_mirrors_the_header():
+    """ffi/rust/hip.rs (uncompiled here: no Rust toolchain) declares the structs of include/rt_hip.h with the same fields
+    in the same order as the ctypes mirror the tests run on, and binds only functions the library exports."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "ffi", "rust", "hip.rs")).read()
+    structs = dict(re.findall(r"#\[repr\(C\)\](?:\s*#\[derive\([^)]*\)\])?\s*pub struct (\w+)\s*\{(.*?)\}", text, flags=re.S))
+    for name in ("RtLight", "RtMaterial", "RtPlane", "RtSphere", "RtTriangle", "RtBvhNode", "RtMesh", "RtMeshInstance",
+                 "RtBackground", "RtSceneDesc", "RtRenderParams", "RtAux"):
+        rust_fields = re.findall(r"pub (\w+)\s*:", structs[name])
+        c_fields = [f[0] for f in getattr(abi, name)._fields_]
+        assert [f.replace("kind", "type") for f in rust_fields] == c_fields, name
+    assert int(re.search(r"RT_N_COUNTERS: usize = (\d+)", text).group(1)) == abi.RT_N_COUNTERS
+    bound = re.findall(r"pub fn (rt_\w+)\s*\(", text.split('extern "C" {')[1].split("\n}")[0])
+    assert bound and set(bound) <= set(native.EXPORTS)
