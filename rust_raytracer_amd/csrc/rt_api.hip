@@ -67,6 +67,7 @@ struct RtScene {
     bool overflow_unreported = false;
     uint32_t capacity_shift = 0;        // lists are (default capacity << capacity_shift) rays long
     bool must_grow = false;             // a frame overflowed: the next one needs lists longer than it had
+    uint32_t walk_contiguous = 0;       // see DFrame::walk_contiguous
     void* scratch = nullptr;            // this device's copy of the static scratch array (rt_render_device_noalloc)
     uint32_t regrown = 0;               // times rt_render had to enlarge the lists for its last frame
     std::vector<void*> scene_allocs;
@@ -520,6 +521,11 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device_id, RtScene**
     if (hipHostMalloc((void**)&s->h_overflow, sizeof(unsigned int), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&s->d_overflow, const_cast<unsigned int*>(s->h_overflow), 0) != hipSuccess)
         return bail(fail(RT_ERR_DEVICE, "cannot allocate the host-visible overflow flag"));
+    // Scenes whose walk data (4-wide nodes + triangles) is far beyond the eight 4 MB L2s: neighbouring pairs walk the same
+    // meshes, so the BVH walk hands them out in runs (2.6 M-triangle grid: 7.5 -> 6.2 ms per frame); cache-resident scenes
+    // keep the interleaving that balances the waves (contiguous runs there: 1.24 -> 1.40 ms)
+    s->walk_contiguous = (nodes4.size() + hot.size()) * sizeof(float4) > (64u << 20);
+    if (const char* env = getenv("RT_WALK_CONTIGUOUS")) s->walk_contiguous = atoi(env) != 0;
     *s->h_overflow = 0;
     if ((rc = scratch_for_device(device_id, &s->scratch))) return bail(rc);
     *out_scene = s;
@@ -662,6 +668,7 @@ static void fill_frame(const RtScene* s, const Geometry& g, uint32_t max_depth, 
     f->n_local_tiles = g.tiles_per_shard; f->view_pixels = g.view_pixels; f->n_views = s->n_views; f->n_pixels = g.n_pixels;
     f->max_depth = max_depth;
     f->overflow = s->d_overflow;
+    f->walk_contiguous = s->walk_contiguous;
 }
 
 static int ensure_frame(RtScene* s, const Geometry& g, uint32_t max_depth, bool aux) {

@@ -169,6 +169,7 @@ struct DFrame {
     unsigned int* slow_flags;        // [RT_MAX_DEPTH_LIMIT + 2] set when a depth has such rays
     uint2* spill;                    // traversal stack entries beyond DScene::stack_lds: entry e of walking lane g at [e * spill_lanes + g]
     uint32_t spill_lanes;            // lanes of the BVH walk's grid
+    uint32_t walk_contiguous;        // the walk hands out runs of neighbouring pairs instead of interleaving them
     unsigned int* chunk_counter;     // [RT_MAX_DEPTH_LIMIT + 2] input chunks of the BVH walk handed out so far, per depth
     float4* hits[2];                 // Phong-shaded hits waiting for their shadow rays, 3 float4 each
     unsigned int* hit_counts[2];     // [n_seg]

@@ -1129,6 +1129,8 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
     // With less than 64 pairs per wave the chunks shrink, so that every wave gets some and shares the long ones.
     const bool one_chunk_each = (unsigned long long)n_waves * RT_WAVE >= n_items;
     const uint32_t n_chunks = one_chunk_each ? n_waves : (n_items + RT_WAVE - 1) / RT_WAVE;
+    const bool contiguous = F.walk_contiguous != 0;
+    const uint32_t chunk_len = (n_items + n_chunks - 1) / n_chunks;
     uint32_t my_chunk = gwave, cur_chunk = 0, chunk_next = 0, chunk_end = 0;       // wave-uniform
     bool exhausted = false;
 
@@ -1215,12 +1217,14 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
                     }
                     my_chunk = n_waves + taken;
                 }
-                // chunk c holds the pairs c, c + n_chunks, c + 2 * n_chunks, ...
-                if (my_chunk >= n_chunks || my_chunk >= n_items) exhausted = true;
+                // chunk c holds the pairs c, c + n_chunks, c + 2 * n_chunks, ... (or, for scenes far larger than the caches,
+                // the run c * chunk_len .. of neighbouring pairs, which walk the same meshes)
+                if (my_chunk >= n_chunks || (contiguous ? (unsigned long long)my_chunk * chunk_len : my_chunk) >= n_items) exhausted = true;
                 else {
                     cur_chunk = my_chunk;
                     chunk_next = 0;
-                    chunk_end = (n_items - my_chunk + n_chunks - 1) / n_chunks;
+                    chunk_end = contiguous ? (n_items - my_chunk * chunk_len < chunk_len ? n_items - my_chunk * chunk_len : chunk_len)
+                                           : (n_items - my_chunk + n_chunks - 1) / n_chunks;
                     my_chunk = 0xFFFFFFFFu;                          // the next one is asked for when it is needed
                 }
             }
@@ -1232,7 +1236,8 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
                 if (rank < avail) {
                     // Element j of chunk c is pair c + j * n_chunks: neighbouring pairs (similar rays, similar cost) go to
                     // different chunks.  A 64-byte item is a cache line of its own either way.
-                    const size_t fat = locate(pre, F.n_seg, F.seg_fat, cur_chunk + (chunk_next + rank) * n_chunks);
+                    const size_t fat = locate(pre, F.n_seg, F.seg_fat, contiguous ? cur_chunk * chunk_len + chunk_next + rank
+                                                                                : cur_chunk + (chunk_next + rank) * n_chunks);
                     const float4 q0 = F.fat_items[4 * fat], q1 = F.fat_items[4 * fat + 1], q2 = F.fat_items[4 * fat + 2],
                                  q3 = F.fat_items[4 * fat + 3];
                     lr.o = mk(q0.x, q0.y, q0.z);
