@@ -265,10 +265,16 @@ def main():
     # Set-up, not warm-up: the first pass on a handle allocates its ray lists, the first gather creates the
     # communicator, and a pass whose ray lists overflow makes the next one on that handle allocate longer ones.
     for s in every_slot:
-        for _ in range(2):
+        for attempt in range(6):
             s.step()
             torch.cuda.synchronize()
-        s.dev.last_ray_counts()                        # raises if the lists are still too short
+            try:
+                s.dev.last_ray_counts()                # raises while the lists are too short or the exact-path kernel was still off
+                if attempt:
+                    break
+            except native.RtError:
+                if attempt == 5:
+                    raise
     for k in range(-(-args.warmup // views)):          # the warm-up frames, in passes like the timed ones
         slots[k % depth].step()
     regions = []

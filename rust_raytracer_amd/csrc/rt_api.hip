@@ -19,7 +19,7 @@
 extern "C" {
 hipError_t rt_launch_generate(const DFrame* F, const DViews* V, uint32_t blocks, hipStream_t stream);
 hipError_t rt_launch_level(const DScene* S, const DFrame* F, uint32_t level, uint32_t blocks, uint32_t traverse_blocks,
-                           hipStream_t stream, hipEvent_t* marks);
+                           hipStream_t stream, hipEvent_t* marks);      // launches rt_setup_slow iff F->slow_launched
 hipError_t rt_launch_resolve(const DFrame* F, uint8_t* out, uint32_t bytes_per_pixel, uint32_t tiled, hipStream_t stream);
 hipError_t rt_launch_resolve_aux(const DFrame* F, uint32_t* prim, uint32_t* inst, uint8_t* flags, float* hit_t, hipStream_t stream);
 hipError_t rt_launch_assemble(const uint8_t* gathered, uint8_t* frame, uint32_t width, uint32_t height, uint32_t tiles_x,
@@ -65,6 +65,11 @@ struct RtScene {
     uint32_t frame_seq = 0;             // sequence number of the last frame enqueued on this handle
     uint32_t overflow_seen = 0;
     bool overflow_unreported = false;
+    // Second word of the same mapping: the sequence number of a frame that held rays for the exact path (rt_setup_slow)
+    // while that kernel was not being launched.  Such a frame is invalid like one whose lists overflowed; from then on the
+    // handle launches the kernel at every depth.
+    uint32_t slow_seen = 0;
+    bool slow_enabled = false;          // rt_setup_slow is launched at every depth
     uint32_t capacity_shift = 0;        // lists are (default capacity << capacity_shift) rays long
     bool must_grow = false;             // a frame overflowed: the next one needs lists longer than it had
     uint32_t walk_contiguous = 0;       // see DFrame::walk_contiguous
@@ -518,7 +523,7 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device_id, RtScene**
     if (bpc < 1) return bail(fail(RT_ERR_DEVICE, "the traversal kernel does not fit a compute unit"));
     if (const char* env = getenv("RT_BLOCKS_PER_CU")) { int v = atoi(env); if (v >= 1 && v <= bpc) bpc = v; }
     s->traverse_blocks = (uint32_t)(s->n_cus * bpc);
-    if (hipHostMalloc((void**)&s->h_overflow, sizeof(unsigned int), hipHostMallocMapped) != hipSuccess ||
+    if (hipHostMalloc((void**)&s->h_overflow, 2 * sizeof(unsigned int), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&s->d_overflow, const_cast<unsigned int*>(s->h_overflow), 0) != hipSuccess)
         return bail(fail(RT_ERR_DEVICE, "cannot allocate the host-visible overflow flag"));
     // Scenes whose walk data (4-wide nodes + triangles) is far beyond the eight 4 MB L2s: neighbouring pairs walk the same
@@ -526,7 +531,12 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device_id, RtScene**
     // keep the interleaving that balances the waves (contiguous runs there: 1.24 -> 1.40 ms)
     s->walk_contiguous = (nodes4.size() + hot.size()) * sizeof(float4) > (64u << 20);
     if (const char* env = getenv("RT_WALK_CONTIGUOUS")) s->walk_contiguous = atoi(env) != 0;
-    *s->h_overflow = 0;
+    s->h_overflow[0] = 0;
+    s->h_overflow[1] = 0;
+    // In a scene whose instances all have culling boxes only stray rays (non-finite or huge components) need the exact
+    // path - none at all in ordinary scenes: the kernel is left out until a frame turns out to need it.
+    s->slow_enabled = !s->d.all_cullable;
+    if (const char* env = getenv("RT_ALWAYS_LAUNCH_SLOW")) s->slow_enabled = s->slow_enabled || atoi(env) != 0;
     if ((rc = scratch_for_device(device_id, &s->scratch))) return bail(rc);
     *out_scene = s;
     return RT_OK;
@@ -668,6 +678,8 @@ static void fill_frame(const RtScene* s, const Geometry& g, uint32_t max_depth, 
     f->n_local_tiles = g.tiles_per_shard; f->view_pixels = g.view_pixels; f->n_views = s->n_views; f->n_pixels = g.n_pixels;
     f->max_depth = max_depth;
     f->overflow = s->d_overflow;
+    f->needs_slow = s->d_overflow + 1;
+    f->slow_launched = s->slow_enabled ? 1u : 0u;
     f->walk_contiguous = s->walk_contiguous;
 }
 
@@ -746,7 +758,13 @@ static int scratch_for_device(int device, void** out) {
 
 // The host sees a frame's overflow through the word the kernels store sequence numbers to.
 static void note_overflow(RtScene* s) {
-    const uint32_t o = *s->h_overflow;
+    const uint32_t slow = s->h_overflow[1];
+    if (slow != s->slow_seen) {
+        s->slow_seen = slow;
+        s->overflow_unreported = true;
+        s->slow_enabled = true;            // from now on the exact-path kernel runs at every depth
+    }
+    const uint32_t o = s->h_overflow[0];
     if (o != s->overflow_seen) {
         s->overflow_seen = o;
         s->overflow_unreported = true;
@@ -901,9 +919,9 @@ extern "C" int rt_render(RtScene* s, const RtRenderParams* p, uint8_t* out_pixel
         }
         HIP_TRY(hipMemcpyAsync(out_pixels, s->d_pixels, bytes, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        const uint32_t seen = s->overflow_seen;
+        const uint32_t seen = s->overflow_seen, seen_slow = s->slow_seen;
         note_overflow(s);
-        if (s->overflow_seen == seen) break;
+        if (s->overflow_seen == seen && s->slow_seen == seen_slow) break;
         // a ray list did not fit: the lists get longer (note_overflow) and the frame is rendered again, which is all
         // the report this overflow needs
         s->overflow_unreported = owed;
@@ -952,8 +970,9 @@ extern "C" int rt_last_ray_counts(RtScene* s, uint64_t counters[RT_N_COUNTERS]) 
     note_overflow(s);
     if (s->overflow_unreported) {
         s->overflow_unreported = false;
-        return fail(RT_ERR_OUT_OF_RANGE, "a ray list overflowed in a frame rendered since the last query (the latest such frame is number %u of "
-                    "this handle, %u have been enqueued): its output is incomplete; the next frame gets longer lists", s->overflow_seen, s->frame_seq);
+        return fail(RT_ERR_OUT_OF_RANGE, "a frame rendered since the last query is incomplete: a ray list overflowed (latest such frame: number %u of "
+                    "this handle) or rays needed the exact path while it was switched off (latest: %u); %u frames have been enqueued, the next one "
+                    "gets longer lists / the exact path", s->overflow_seen, s->slow_seen, s->frame_seq);
     }
     uint64_t sums[8];
     int rc = sum_wave_stats(s, sums);

@@ -179,4 +179,8 @@ struct DFrame {
     // so the word names the latest frame that overflowed.
     unsigned int* overflow;
     uint32_t overflow_seq;           // this frame's sequence number on its handle, never 0
+    // rt_setup_slow is only launched when slow_launched is set; a frame that turns out to hold rays for it while it is
+    // not stores its sequence number to *needs_slow (host-mapped, like *overflow) and is invalid.
+    unsigned int* needs_slow;
+    uint32_t slow_launched;
 };

@@ -754,6 +754,9 @@ __global__ void __launch_bounds__(RT_SETUP_THREADS) rt_setup(const DScene S, con
         {
             const uint32_t slot = append_slot(active && !easy, &slow_n, F.seg_rays, F.n_seg, F.slow_counts, F.ovf_rays, F.overflow, F.overflow_seq, lane);
             if (slot != RT_REF_NONE) F.slow_rays[slot] = gi;
+            // whatever happens to such a ray (rt_setup_slow may not be launched for this frame, its list may be full - either
+            // way the frame is invalid), the later kernels must find a well-formed key
+            if (active && !easy) F.best[gi] = RT_KEY_NONE;
         }
         active = active && easy;
         const bool early = ss.is_shadow;
@@ -865,7 +868,10 @@ __global__ void __launch_bounds__(RT_SETUP_THREADS) rt_setup(const DScene S, con
     if (threadIdx.x == 0) {
         F.item_counts[blockIdx.x] = out_n < F.seg_items ? out_n : F.seg_items;
         F.slow_counts[blockIdx.x] = slow_n < F.seg_rays ? slow_n : F.seg_rays;
-        if (slow_n) F.slow_flags[level] = 1u;
+        if (slow_n) {
+            F.slow_flags[level] = 1u;
+            if (!F.slow_launched) *F.needs_slow = F.overflow_seq;      // nobody will trace these rays: the frame has to be redone
+        }
     }
 }
 
@@ -1788,8 +1794,9 @@ extern "C" hipError_t rt_launch_level(const DScene* S, const DFrame* F, uint32_t
     // In a scene whose instances all have culling boxes only stray rays (NaN components) reach this kernel, if any:
     // a small grid keeps the usual empty launch cheap.  (Block b continues list segment b, so any grid <= blocks works.)
     const uint32_t slow_blocks = (S->all_cullable && blocks > 64) ? 64 : blocks;
-    hipLaunchKernelGGL(rt_setup_slow, dim3(slow_blocks), dim3(RT_BLOCK_THREADS), lds + analytic_stage_words(*S) * sizeof(uint32_t), stream,
-                       *S, *F, level);
+    if (F->slow_launched)
+        hipLaunchKernelGGL(rt_setup_slow, dim3(slow_blocks), dim3(RT_BLOCK_THREADS), lds + analytic_stage_words(*S) * sizeof(uint32_t), stream,
+                           *S, *F, level);
     if (marks) (void)hipEventRecord(marks[1], stream);
     if (S->n_instances > 0)
         hipLaunchKernelGGL(rt_root, dim3(blocks), dim3(RT_ROOT_THREADS), lds, stream, *S, *F, level);

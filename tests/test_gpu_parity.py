@@ -348,6 +348,41 @@ def test_overflow_of_a_device_frame_is_reported_once(scenes_dir, model_dir):
         dev.close()
 
 
+def test_stray_rays_switch_the_exact_path_on(scenes_dir, model_dir):
+    """The kernel that traces rays with non-finite components in the reference's own order is left out of the launch
+    sequence until a frame turns out to hold such rays (here: a camera matrix with a NaN in it, so that every primary
+    ray has a NaN component).  That frame is reported as incomplete once, like a list overflow; from the next frame on
+    the kernel runs and the picture is the one rt_render (which redoes such a frame itself) delivers."""
+    import torch
+    s = load(scenes_dir, model_dir, "reflective_bunnies", 320, 180)
+    m, w, h = s.camera()
+    m = np.array(m, dtype=np.float32)
+    m[1] = np.nan
+    s.set_camera_matrix(m, w, h)
+    dev = native.DeviceScene(s.desc(), 0)
+    fresh = native.DeviceScene(s.desc(), 0)
+    try:
+        dev.set_camera(m, w, h)
+        fresh.set_camera(m, w, h)
+        side = torch.cuda.Stream()
+        torch.cuda.set_stream(side)
+        out = torch.zeros(h * w * 3, dtype=torch.uint8, device="cuda")
+        dev.render_device(out.data_ptr(), max_depth=16, stream=side.cuda_stream)
+        with pytest.raises(native.RtError) as e:
+            dev.last_ray_counts()
+        assert e.value.code == abi.RT_ERR_OUT_OF_RANGE and "exact path" in str(e.value)
+        dev.render_device(out.data_ptr(), max_depth=16, stream=side.cuda_stream)
+        counts = dev.last_ray_counts()
+        got = fresh.render(max_depth=16, aux=True)                       # redone inside rt_render
+        want = s.render(max_depth=16)
+        assert_parity(got, want)
+        assert np.array_equal(out.cpu().numpy().reshape(h, w, 3), got["rgb"])
+        assert counts[:5].tolist() == want["counters"][:5].tolist()
+    finally:
+        dev.close()
+        fresh.close()
+
+
 def test_no_lights_and_empty_scene(scenes_dir, model_dir):
     scene = json.load(open(os.path.join(scenes_dir, "cornell_box.json")))
     scene["lights"] = []
