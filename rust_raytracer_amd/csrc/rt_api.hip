@@ -646,7 +646,7 @@ static int carve_frame(uint32_t n_pixels, uint32_t n_lights, uint32_t blocks, ui
     };
     if ((rc = get(sz->pixel_clear_bytes / sizeof(long long) + 1, &f.acc)) || (rc = get(sz->counter_words, &counters)) ||
         (rc = get((size_t)3 * n_pixels, &f.acc_big)) ||
-        (rc = get(2 * all_ray_slots, &f.rays[0])) || (rc = get(2 * all_ray_slots, &f.rays[1])) ||
+        (rc = get(2 * ray_slots, &f.rays[0])) || (rc = get(2 * ray_slots, &f.rays[1])) ||      // shadow rays are not stored
         (rc = get(all_ray_slots, &f.best)) ||
         (rc = get(item_slots, &f.items)) || (rc = get(item_slots, &f.item_results)) ||
         (rc = get(4 * fat_slots, &f.fat_items)) || (rc = get(ray_slots, &f.slow_rays)) ||

@@ -151,10 +151,11 @@ struct DFrame {
     unsigned int* aux_prim;          // [n_pixels] or null
     unsigned int* aux_inst;          // [n_pixels] or null
     float* aux_t;                    // [n_pixels] or null: t of the primary hit
-    // Ray records of the current / next depth, 2 float4 each.  Slots below shadow_base form the segmented list
-    // of the primary / reflected / transmitted rays; the shadow ray of hit record h towards light l has the fixed
-    // slot shadow_base + h * n_lights + l (raytracer.rs:77-79: one per light per Phong-shaded hit), so the shadow
-    // rays of a depth are enumerated through the hit list and nobody has to append or look them up.
+    // Ray records of the current / next depth, 2 float4 each: the segmented list of the primary / reflected /
+    // transmitted rays, slots below shadow_base.  The shadow ray of hit record h towards light l has the fixed slot number
+    // shadow_base + h * n_lights + l (raytracer.rs:77-79: one per light per Phong-shaded hit) - a number for its candidate
+    // key in `best` and for the walk items, not a record: the ray itself is rebuilt from the hit record wherever it is
+    // needed (shadow_rec in rt_kernels.hip), so the shadow rays of a depth cost no ray traffic at all.
     float4* rays[2];
     uint32_t shadow_base;
     unsigned int* ray_counts[2];     // [n_seg]

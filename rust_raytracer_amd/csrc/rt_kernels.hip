@@ -319,6 +319,7 @@ __device__ __forceinline__ void add_color(const DFrame& F, uint32_t pixel, V3 c)
 #define RT_META_KIND_SHIFT 25            // 0 = primary / reflected, 1 = transmitted
 #define RT_META_DEPTH_SHIFT 26
 
+#define RT_RAY_SHADOW_BIT 0x80000000u    // = RT_RAY_SHADOW, see the work lists below
 struct RayRec { Ray ray; float throughput; uint32_t meta; };
 
 __device__ __forceinline__ void store_rec(float4* q, uint32_t i, const RayRec& rr) {
@@ -333,6 +334,32 @@ __device__ __forceinline__ RayRec load_rec(const float4* q, uint32_t i) {
     rr.throughput = b.z;
     rr.meta = __float_as_uint(b.w);
     return rr;
+}
+
+// Shadow rays are not stored: the shadow ray of hit record `hs` towards light `li` (ray slot shadow_base + hs * n_lights
+// + li) is rebuilt from the record wherever it is needed - trace_shadow_ray's own arithmetic (raytracer.rs:158-167) on the
+// stored hit position, so the same bits every time.
+__device__ __forceinline__ RayRec shadow_rec(const DScene& S, const float4* hits, uint32_t hs, uint32_t li) {
+    const float4 h0 = hits[3 * (size_t)hs];
+    const DLight& L = S.lights[li];
+    const V3 position = mk(h0.x, h0.y, h0.z);
+    const V3 dir = (L.pos[3] == 0.0f) ? mk(L.pos[0], L.pos[1], L.pos[2]) : ld3(L.world) - position;
+    RayRec rr;
+    rr.ray.o = position;
+    rr.ray.d = normalize3(dir);
+    rr.throughput = 0.0f;
+    rr.meta = RT_RAY_SHADOW_BIT | li;
+    return rr;
+}
+// Any ray of recursion depth `level` by its slot: listed rays from the ray list, shadow rays from the hits of the depth above.
+__device__ __forceinline__ RayRec load_any_rec(const DScene& S, const DFrame& F, uint32_t level, uint32_t gi) {
+    if (gi < F.shadow_base) return load_rec(F.rays[level & 1], gi);
+    const uint32_t k = gi - F.shadow_base, hs = k / S.n_lights;
+    return shadow_rec(S, F.hits[(level & 1) ^ 1], hs, k - hs * S.n_lights);
+}
+__device__ __forceinline__ V3 load_any_origin(const DScene& S, const DFrame& F, uint32_t level, uint32_t gi) {
+    const float4 a = gi < F.shadow_base ? F.rays[level & 1][2 * (size_t)gi] : F.hits[(level & 1) ^ 1][3 * (size_t)((gi - F.shadow_base) / S.n_lights)];
+    return mk(a.x, a.y, a.z);
 }
 
 // local pixel index -> view and canvas (col, row); false for padding pixels outside the frame
@@ -735,9 +762,9 @@ __global__ void __launch_bounds__(RT_SETUP_THREADS) rt_setup(const DScene S, con
             const uint32_t cs = c - main_chunks, light = cs / hit_chunks, first = (cs - light * hit_chunks) * RT_WAVE;
             const uint32_t hs = locate_chunk(pre_hits, F.n_seg, F.seg_hits, first, n_hits, lane);
             active = first + lane < n_hits;
-            if (active) gi = F.shadow_base + hs * S.n_lights + light;
+            if (active) { gi = F.shadow_base + hs * S.n_lights + light; rr = shadow_rec(S, F.hits[p ^ 1], hs, light); }
         }
-        if (active) rr = load_rec(rays, gi);
+        if (active && c < main_chunks) rr = load_rec(rays, gi);
         const Ray r = rr.ray;
         const ShadowSpec ss = shadow_spec(S, rr);
 #ifdef RT_STATS
@@ -888,7 +915,6 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_setup_slow(const DScene S
     uint32_t* scratch = lds + F.n_seg + 1;     // blockDim.x
     __shared__ uint32_t out_n;
     if (threadIdx.x == 0) out_n = F.item_counts[blockIdx.x];        // this block's segment continues where rt_setup stopped
-    const uint32_t p = level & 1;
     const uint32_t n_rays = build_prefix(F.slow_counts, F.n_seg, F.seg_rays, F.ovf_rays, pre, scratch);
     // the analytic primitives are staged in LDS (every lane reads the same one: a broadcast, no scalar-load
     // round trip per primitive)
@@ -909,7 +935,6 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_setup_slow(const DScene S
         }
         __syncthreads();
     }
-    const float4* rays = F.rays[p];
     const uint32_t lane = threadIdx.x & (RT_WAVE - 1);
     const uint32_t gwave = (blockIdx.x * blockDim.x + threadIdx.x) / RT_WAVE;
     const uint32_t n_waves = gridDim.x * (blockDim.x / RT_WAVE);
@@ -922,7 +947,7 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_setup_slow(const DScene S
         rr.ray.o = rr.ray.d = mk(0, 0, 0);
         rr.throughput = 0.0f;
         rr.meta = 0;
-        if (active) { gi = F.slow_rays[locate(pre, F.n_seg, F.seg_rays, v)]; rr = load_rec(rays, gi); }
+        if (active) { gi = F.slow_rays[locate(pre, F.n_seg, F.seg_rays, v)]; rr = load_any_rec(S, F, level, gi); }
         const Ray r = rr.ray;
         const ShadowSpec ss = shadow_spec(S, rr);
         const bool ray_finite = finite3(r.o) && finite3(r.d);
@@ -1031,7 +1056,6 @@ __global__ void __launch_bounds__(RT_ROOT_THREADS) rt_root(const DScene S, const
     __shared__ uint32_t out_n;
     if (threadIdx.x == 0) out_n = 0;
     const uint32_t n_items = build_prefix(F.item_counts, F.n_seg, F.seg_items, F.ovf_items, pre, scratch);
-    const float4* rays = F.rays[level & 1];
     const uint32_t lane = threadIdx.x & (RT_WAVE - 1);
     const uint32_t gwave = (blockIdx.x * blockDim.x + threadIdx.x) / RT_WAVE;
     const uint32_t n_waves = gridDim.x * (blockDim.x / RT_WAVE);
@@ -1044,7 +1068,7 @@ __global__ void __launch_bounds__(RT_ROOT_THREADS) rt_root(const DScene S, const
             const uint2 it = F.items[item];
             if (!(it.y & RT_ITEM_DONE)) {
                 const uint32_t gi = it.x, ii = it.y;
-                const RayRec rr = load_rec(rays, gi);
+                const RayRec rr = load_any_rec(S, F, level, gi);
                 const ShadowSpec ss = shadow_spec(S, rr);
                 const DInstance& inst = S.instances[ii];
                 const float o_l1 = fabsf(rr.ray.o.x) + fabsf(rr.ray.o.y) + fabsf(rr.ray.o.z);
@@ -1128,7 +1152,6 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
     uint32_t* donor_list = scratch + wave * RT_WAVE;               // free again once the prefix table is built
     const uint32_t gwave = (blockIdx.x * blockDim.x + threadIdx.x) / RT_WAVE;
     const uint32_t n_waves = gridDim.x * (blockDim.x / RT_WAVE);
-    const float4* rays = F.rays[level & 1];
 
     // Input is handed out in chunks of 64 pairs: every wave starts with the chunk of its own index, further ones
     // come from a counter in device memory (one atomic per 64 pairs), so that waves with light pairs take more.
@@ -1206,8 +1229,7 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
                             triangle_tuv(mk(h0.x, h0.y, h0.z), mk(h0.w, h1.x, h1.y), mk(h1.z, h1.w, h2.x), lr, m_t, m_u, m_v);
                             m_slot = win_slot;
                         }
-                        const float4 w0 = rays[2 * (size_t)gi];                  // the ray's world origin
-                        float tw = world_t(S, S.instances[ii], lr, mk(w0.x, w0.y, w0.z), m_t, m_slot);
+                        float tw = world_t(S, S.instances[ii], lr, load_any_origin(S, F, level, gi), m_t, m_slot);      // from the ray's world origin
                         F.item_results[item] = make_float4(m_t, m_u, m_v, __uint_as_float(m_slot));
                         atomicMin(&F.best[gi], make_key(tw, RT_KEY_MESH | item));
                     }
@@ -1640,20 +1662,8 @@ __global__ void __launch_bounds__(RT_SHADE_THREADS) rt_shade(const DScene S, con
             H[1] = make_float4(hit.hit_normal.x, hit.hit_normal.y, hit.hit_normal.z, cur.throughput);
             H[2] = make_float4(-cur.ray.d.x, -cur.ray.d.y, -cur.ray.d.z, __uint_as_float(pixel | (level == 0 ? RT_HIT_DEPTH0 : 0u)));
         }
-        if (hit_slot != RT_REF_NONE) {
-            for (uint32_t li = 0; li < S.n_lights; ++li) {
-                const DLight& L = S.lights[li];
-                const bool directional = L.pos[3] == 0.0f;
-                V3 dir = directional ? mk(L.pos[0], L.pos[1], L.pos[2]) : ld3(L.world) - hit.position;      // raytracer.rs:158-167
-                RayRec sr;
-                sr.ray.o = hit.position;
-                sr.ray.d = normalize3(dir);
-                sr.throughput = 0.0f;
-                sr.meta = RT_RAY_SHADOW | li;
-                store_rec(rays_out, F.shadow_base + hit_slot * S.n_lights + li, sr);      // its fixed slot, see DFrame::rays
-                ++n_shadow;
-            }
-        }
+        // one shadow ray per light (raytracer.rs:77-79), traced at the next depth straight from the hit record (shadow_rec)
+        if (hit_slot != RT_REF_NONE) n_shadow += S.n_lights;
         {
             const uint32_t slot = append_slot(emit_r, &out_rays, F.seg_rays, F.n_seg, F.ray_counts[q], F.ovf_rays, F.overflow, F.overflow_seq, lane);
             if (slot != RT_REF_NONE) store_rec(rays_out, slot, rec_r);
