@@ -4,6 +4,7 @@ sys.path.insert(0, '/root/repo')
 import numpy as np, torch
 import bench
 from rust_raytracer_amd import meshes, native, synthetic
+views = int(os.environ.get('VIEWS', '1'))
 names = sys.argv[1:] or ['reflective_bunnies_1080p']
 for name in names:
     scene_file, width, height, max_depth = bench.WORKLOADS[name]
@@ -18,8 +19,8 @@ for name in names:
         host = native.HostScene.load('/root/repo/scenes/' + scene_file, meshes.ensure_model_dir())
     host.resize_screen(width, height)
     dev = native.DeviceScene(host.desc(), 0)
-    m, w, h = host.camera(); dev.set_camera(m, w, h)
-    buf = torch.zeros(w * h * 3, dtype=torch.uint8, device='cuda')
+    m, w, h = host.camera(); dev.set_views(np.tile(np.asarray(m, dtype=np.float32).reshape(1, 16), (views, 1)), w, h)
+    buf = torch.zeros(views * w * h * 3, dtype=torch.uint8, device='cuda')
     for shards in (1, 8):
         for _ in range(3):
             dev.render_device(buf.data_ptr(), max_depth=max_depth, shard_count=shards); dev.last_ray_counts()
@@ -30,13 +31,13 @@ for name in names:
         for _ in range(n):
             dev.render_device(buf.data_ptr(), max_depth=max_depth, shard_count=shards)
             for k, (ms, c) in dev.last_kernel_ms().items():
-                tot[k] = tot.get(k, 0.0) + ms / n
+                tot[k] = tot.get(k, 0.0) + ms / n / views
             frame.append(dev.last_render_ms())
         dev.set_kernel_timing(False)
         plain = []
         for _ in range(n):
             dev.render_device(buf.data_ptr(), max_depth=max_depth, shard_count=shards); dev.last_ray_counts()
             plain.append(dev.last_render_ms())
-        print('%s 1/%d: frame %.3f ms (timed mode %.3f) rays %d | %s' % (name, shards, float(np.median(plain)), float(np.median(frame)), int(dev.last_ray_counts()[0]),
+        print('%s 1/%d: frame %.3f ms (timed mode %.3f) rays %d | %s' % (name, shards, float(np.median(plain)) / views, float(np.median(frame)) / views, int(dev.last_ray_counts()[0]) // views,
               ' '.join('%s %.3f' % (k, v) for k, v in tot.items())), flush=True)
     dev.close(); host.close()
