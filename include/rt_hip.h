@@ -323,7 +323,7 @@ int rt_last_trace_ms(RtScene* scene, float* out_ms);
  * boxes of the surviving (ray, instance) pairs (intersect.rs:296-308), BVH walk (intersect.rs:228-269),
  * shading of the closest hits (raytracer.rs:65-135) together with the Phong sums of the depth above, whose
  * shadow rays are known by then (raytracer.rs:137-187). */
-enum { RT_KERNEL_SETUP = 0, RT_KERNEL_ROOT, RT_KERNEL_TRAVERSE, RT_KERNEL_SHADE, RT_N_LEVEL_KERNELS };
+enum { RT_KERNEL_SETUP = 0, RT_KERNEL_TRAVERSE, RT_KERNEL_SHADE, RT_N_LEVEL_KERNELS };
 
 /* Kernel timing mode (off by default): every launch of the per-depth kernels is bracketed by HIP
  * events on the launch stream.  No counterpart in the reference (its only timing is native_app's

@@ -355,6 +355,8 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device_id, RtScene**
         {desc->mesh_instances, desc->n_mesh_instances, "mesh_instances"}};
     for (auto& a : arrays)
         if (a.n && !a.p) return fail(RT_ERR_INVALID_ARGUMENT, "%s: %u elements but a null pointer", a.name, a.n);
+    if (desc->n_mesh_instances > RT_MAX_INSTANCES)
+        return fail(RT_ERR_OUT_OF_RANGE, "%u mesh instances exceed the limit of %u", desc->n_mesh_instances, RT_MAX_INSTANCES);
     if (desc->background.type > RT_BACKGROUND_COLORED_DIRECTION) return fail(RT_ERR_INVALID_ARGUMENT, "unknown background type %u", desc->background.type);
 
     // ---- flatten on the host --------------------------------------------------------------------
@@ -623,11 +625,9 @@ static int carve_frame(uint32_t n_pixels, uint32_t n_lights, uint32_t blocks, ui
     f.n_seg = blocks + 1;
     auto seg = [&](uint64_t total) { return std::max<uint32_t>(ceil_div(total, blocks), seg_min); };
     f.seg_rays = seg(capacity);          f.ovf_rays = (uint32_t)(capacity / 4 + 1024);
-    f.seg_items = seg(capacity);         f.ovf_items = (uint32_t)(capacity / 4 + 1024);
     f.seg_fat = seg(capacity / 2);       f.ovf_fat = (uint32_t)(capacity / 8 + 1024);
     f.seg_hits = seg(capacity / 2);      f.ovf_hits = (uint32_t)(capacity / 8 + 1024);
     const size_t ray_slots = (size_t)blocks * f.seg_rays + f.ovf_rays;
-    const size_t item_slots = (size_t)blocks * f.seg_items + f.ovf_items;
     const size_t fat_slots = (size_t)blocks * f.seg_fat + f.ovf_fat;
     const size_t hit_slots = (size_t)blocks * f.seg_hits + f.ovf_hits;
     const size_t all_ray_slots = ray_slots + hit_slots * n_lights;      // + the shadow rays, see DFrame::rays
@@ -635,7 +635,7 @@ static int carve_frame(uint32_t n_pixels, uint32_t n_lights, uint32_t blocks, ui
     sz->stats_words = (size_t)std::max<uint32_t>(blocks * 4, spill_lanes / 64) * 8;      // a row per wave of the largest grid
     // colour sums and poison words in one allocation, all counters in another: two clears per frame
     sz->pixel_clear_bytes = (size_t)3 * n_pixels * sizeof(long long) + (size_t)n_pixels * sizeof(unsigned int);
-    sz->counter_words = 7 * (size_t)f.n_seg + 2 * (RT_MAX_DEPTH_LIMIT + 2) + sz->stats_words;
+    sz->counter_words = 6 * (size_t)f.n_seg + 2 * (RT_MAX_DEPTH_LIMIT + 2) + sz->stats_words;
     unsigned int* counters = nullptr;
     int rc;
     auto get = [&](size_t count, auto** p) {
@@ -648,8 +648,7 @@ static int carve_frame(uint32_t n_pixels, uint32_t n_lights, uint32_t blocks, ui
         (rc = get((size_t)3 * n_pixels, &f.acc_big)) ||
         (rc = get(2 * ray_slots, &f.rays[0])) || (rc = get(2 * ray_slots, &f.rays[1])) ||      // shadow rays are not stored
         (rc = get(all_ray_slots, &f.best)) ||
-        (rc = get(item_slots, &f.items)) || (rc = get(item_slots, &f.item_results)) ||
-        (rc = get(4 * fat_slots, &f.fat_items)) || (rc = get(ray_slots, &f.slow_rays)) ||
+        (rc = get(fat_slots, &f.item_results)) || (rc = get(4 * fat_slots, &f.fat_items)) || (rc = get(ray_slots, &f.slow_rays)) ||
         (rc = get(3 * hit_slots, &f.hits[0])) || (rc = get(3 * hit_slots, &f.hits[1])))
         return rc;
     f.shadow_base = (uint32_t)ray_slots;
@@ -657,7 +656,7 @@ static int carve_frame(uint32_t n_pixels, uint32_t n_lights, uint32_t blocks, ui
     if (spill_entries && (rc = get((size_t)spill_entries * spill_lanes, &f.spill))) return rc;
     unsigned int* c = counters;
     f.ray_counts[0] = c; c += f.n_seg;   f.ray_counts[1] = c; c += f.n_seg;
-    f.item_counts = c; c += f.n_seg;     f.fat_counts = c; c += f.n_seg;     f.slow_counts = c; c += f.n_seg;
+    f.fat_counts = c; c += f.n_seg;     f.slow_counts = c; c += f.n_seg;
     f.hit_counts[0] = c; c += f.n_seg;   f.hit_counts[1] = c; c += f.n_seg;
     f.chunk_counter = c; c += RT_MAX_DEPTH_LIMIT + 2;
     f.slow_flags = c; c += RT_MAX_DEPTH_LIMIT + 2;
@@ -1019,7 +1018,7 @@ extern "C" int rt_last_kernel_ms(RtScene* s, float out_ms[RT_N_LEVEL_KERNELS], u
         const hipEvent_t* m = &s->marks[(RT_N_LEVEL_KERNELS + 1) * (size_t)level];
         for (int k = 0; k < RT_N_LEVEL_KERNELS; ++k) {
             const bool launched = k == RT_KERNEL_SETUP || k == RT_KERNEL_SHADE ||
-                                  ((k == RT_KERNEL_TRAVERSE || k == RT_KERNEL_ROOT) && s->d.n_instances > 0);
+                                  (k == RT_KERNEL_TRAVERSE && s->d.n_instances > 0);
             if (!launched) continue;
             float ms = 0.0f;
             HIP_TRY(hipEventElapsedTime(&ms, m[k], m[k + 1]));
@@ -1047,19 +1046,6 @@ extern "C" int rt_debug_last_regrown(RtScene* s, uint32_t* out) {
     return RT_OK;
 }
 
-
-#ifdef RT_STATS
-// diagnostic build: the BVH work items of the last traversal launch and the per-block counts
-extern "C" int rt_debug_items(RtScene* s, uint2* items, unsigned int* counts, uint32_t* geometry /* n_seg, seg_items, ovf_items */) {
-    HIP_TRY(hipSetDevice(s->device));
-    HIP_TRY(hipDeviceSynchronize());
-    const DFrame& f = s->f;
-    geometry[0] = f.n_seg; geometry[1] = f.seg_items; geometry[2] = f.ovf_items;
-    if (items) HIP_TRY(hipMemcpy(items, f.items, ((size_t)(f.n_seg - 1) * f.seg_items + f.ovf_items) * sizeof(uint2), hipMemcpyDeviceToHost));
-    if (counts) HIP_TRY(hipMemcpy(counts, f.item_counts, f.n_seg * sizeof(unsigned int), hipMemcpyDeviceToHost));
-    return RT_OK;
-}
-#endif
 
 extern "C" const char* rt_last_error(void) { return g_error; }
 

@@ -70,9 +70,12 @@ struct DInstance {
 // that starting a walk is one fetch.
 //   q0 = (local origin, entry distance into the root box)     q1 = (local direction, local bound on useful t)
 //   q2 = (1 / |rotation_scale_inverse * d|, shadow threshold, prune_abs, bits root reference)
-//   q3 = (bits ray slot, bits instance | RT_FAT_FAST, bits work item index, 0)
+//   q3 = (bits ray slot, bits instance | flags, 0, 0)
 // shadow threshold: a candidate with local t * q2.x below it proves a shadow ray blocked (-inf for other rays).
-#define RT_FAT_FAST 0x80000000u
+#define RT_FAT_FAST 0x80000000u          // the walk may prune by distance and share subtrees (DInstance::prunable)
+#define RT_FAT_DONE 0x40000000u          // no walk: the pair's result is already in item_results (ray traced on the exact path)
+#define RT_FAT_INSTANCE 0x3FFFFFFFu
+#define RT_MAX_INSTANCES (1u << 20)      // mesh instances of a scene (rt_setup packs the index into 20 bits)
 
 // A child reference: inner node index, or a leaf given by its first triangle slot and its count.
 #define RT_REF_NONE 0xFFFFFFFFu
@@ -141,8 +144,7 @@ struct DFrame {
     uint32_t mode;                   // RT_MODE_*
     uint32_t n_seg;                  // producer blocks + 1 (the last segment is the shared overflow segment)
     uint32_t seg_rays, ovf_rays;     // capacity of a block's ray segment / of the overflow segment
-    uint32_t seg_items, ovf_items;   // (ray, instance) pairs that pass the culling box
-    uint32_t seg_fat, ovf_fat;       // pairs that pass the exact root-box test
+    uint32_t seg_fat, ovf_fat;       // (ray, instance) pairs that pass the exact root-box test: the walk items
     uint32_t seg_hits, ovf_hits;
     long long* acc;                  // [3][n_pixels] fixed-point colour sums, 2^-40 units
     double* acc_big;                 // [3][n_pixels] sums of the rare contributions beyond 2^22
@@ -160,10 +162,8 @@ struct DFrame {
     uint32_t shadow_base;
     unsigned int* ray_counts[2];     // [n_seg]
     unsigned long long* best;        // [ray slots] closest candidate so far: t bits << 32 | order, see rt_kernels.hip
-    uint2* items;                    // BVH work items: (ray slot, instance | flags)
-    float4* item_results;            // per item: local t, u, v, bits triangle slot
-    unsigned int* item_counts;       // [n_seg]
-    float4* fat_items;               // 4 float4 per entry, segmented like the other lists
+    float4* fat_items;               // walk items, 4 float4 per entry, segmented like the other lists
+    float4* item_results;            // per walk item: local t, u, v, bits triangle slot
     unsigned int* fat_counts;        // [n_seg]
     unsigned int* slow_rays;         // ray slots rt_setup left to rt_setup_slow, segmented like the ray lists
     unsigned int* slow_counts;       // [n_seg]

@@ -12,11 +12,11 @@
 //    atomics, so the result does not depend on the order in which rays finish.
 //  * All rays of one recursion depth - and the shadow rays of the hits one depth up - form a list
 //    in HBM (32 B per ray).  Each depth is a sequence of dense launches over such lists:
-//      A   rt_setup       per ray: analytic primitives; per instance a world-space culling box -> one
-//                         (ray, instance) pair per instance the ray can touch
+//      A   rt_setup       per ray: analytic primitives; per instance a world-space culling box -> the
+//                         (ray, instance) pairs the ray can touch; per pair, 64 pairs at a time: the mesh-local
+//                         ray and the exact root-box test -> 64-byte walk item
 //      A'  rt_setup_slow  the few rays rt_setup does not treat (non-finite components, degenerate instance
-//                         matrices), in the reference's exact evaluation order; usually an empty launch
-//      A2  rt_root        per pair: the mesh-local ray and the exact root-box test -> 64-byte walk item
+//                         matrices), in the reference's exact evaluation order; only launched for scenes that need it
 //      B   rt_traverse    BVH walk, one walk item per lane, lanes refilled as they finish - every lane
 //                         that is busy is busy with the same code
 //      C   rt_shade       closest hit -> hit point, material, child rays and shadow rays; then the Phong sums
@@ -41,9 +41,6 @@
 // measured to change nothing on the 1080p bunnies frame, so all stay at 256.
 #ifndef RT_SETUP_THREADS
 #define RT_SETUP_THREADS 256
-#endif
-#ifndef RT_ROOT_THREADS
-#define RT_ROOT_THREADS 256
 #endif
 #ifndef RT_SHADE_THREADS
 #define RT_SHADE_THREADS 256
@@ -399,7 +396,6 @@ __device__ __forceinline__ Ray primary_ray(const DFrame& F, const float* m, uint
 
 #define RT_KEY_NONE 0xFFFFFFFFFFFFFFFFull
 #define RT_KEY_MESH 0x80000000u          // low word: bit 31 set = BVH work item index, clear = analytic primitive
-#define RT_ITEM_DONE 0x80000000u         // item.y flag: result already final (ray traced on the exact path)
 #define RT_RAY_SHADOW 0x80000000u        // ray meta: shadow ray; low 8 bits = light index, record.w = bits(hit slot)
 #define RT_HIT_DEPTH0 0x80000000u        // hit record pixel word: the hit belongs to a primary ray
 
@@ -597,6 +593,100 @@ __device__ __forceinline__ ShadowSpec shadow_spec(const DScene& S, const RayRec&
     return s;
 }
 
+// The 64-byte walk item of a (ray, instance) pair (see RT_FAT_FAST in rt_device.h): the mesh-local ray of
+// intersect.rs:296-308 and the test of the mesh's root box (the first iteration of intersect.rs:245-250).
+// `lw`: world distance beyond which nothing on this ray matters any more (closest analytic hit, light of a shadow
+// ray; +inf if none).  Returns false when the pair needs no walk.
+__device__ __forceinline__ bool walk_item(const DInstance& inst, uint32_t ii, uint32_t gi, const Ray& r, const ShadowSpec& ss, float lw,
+                                          float4& q0, float4& q1, float4& q2, float4& q3) {
+    const float o_l1 = fabsf(r.o.x) + fabsf(r.o.y) + fabsf(r.o.z);
+    Ray lr;
+    lr.o = transform34(inst.model_inverse, r.o);
+    const V3 dv = transform34(inst.rotation_scale_inverse, r.d);
+    const float dn = sqrtf(dot3(dv, dv));
+    lr.d = mk(dv.x / dn, dv.y / dn, dv.z / dn);                 // glm::normalize, intersect.rs:304-308
+    const V3 inv = mk(1.0f / lr.d.x, 1.0f / lr.d.y, 1.0f / lr.d.z);
+    const bool fast = inst.prunable != 0;
+    const float slack_w = 2.0f * inst.world_guard;
+    // mesh-local bound on useful t: a hit at world distance w lies at local t = w * dn (up to world_guard)
+    float limit = RT_INF;
+    if (fast && lw < RT_INF) limit = (lw + slack_w + 1.52587890625e-05f * (o_l1 + lw)) * dn * 1.0009765625f;
+    float root_tmin;
+    bool pass = slab(inst.root_lo[0], inst.root_lo[1], inst.root_lo[2], inst.root_hi[0], inst.root_hi[1], inst.root_hi[2],
+                     lr.o, inv, root_tmin);
+    if (pass && fast && root_tmin > limit * RT_PRUNE_REL + inst.prune_abs) pass = false;
+    // Shadow rays: a candidate at local t lies within world_guard of world distance t / dn, and the pair's
+    // final hit is not farther than any candidate.
+    float thr = -RT_INF;
+    if (ss.is_shadow) thr = ss.directional ? RT_INF : ss.limit_world - (1.5f * slack_w + 6.103515625e-05f * (o_l1 + ss.limit_world));
+    q0 = make_float4(lr.o.x, lr.o.y, lr.o.z, root_tmin);
+    q1 = make_float4(lr.d.x, lr.d.y, lr.d.z, limit);
+    q2 = make_float4(1.0f / dn, thr, inst.prune_abs, __uint_as_float(inst.root_ref4));
+    q3 = make_float4(__uint_as_float(gi), __uint_as_float(ii | (fast ? RT_FAT_FAST : 0u)), 0.0f, 0.0f);
+    return pass;
+}
+
+__device__ __forceinline__ void store_walk_item(float4* fat_items, uint32_t slot, float4 q0, float4 q1, float4 q2, float4 q3) {
+    fat_items[4 * (size_t)slot] = q0; fat_items[4 * (size_t)slot + 1] = q1;
+    fat_items[4 * (size_t)slot + 2] = q2; fat_items[4 * (size_t)slot + 3] = q3;
+}
+
+// ---- the pairs of a wave waiting for their walk items (rt_setup) ----------------------------------------------------
+// A ray passes the culling boxes of some instances only, so the lanes that have a pair for a given instance are few; the
+// local ray and the root test are therefore not computed in place but for 64 pairs at a time: the wave keeps its pairs
+// in a ring in LDS (first in, first out: a ray's pairs stay in the instances' Vec order, which the slots of the walk
+// items must keep, see RT_KEY_MESH), and whenever 64 are waiting one lane takes one pair each.
+#define RT_RING_CAP 128                   // at most 63 pairs are left over when at most 64 more arrive
+#define RT_RING_WORDS (9 * RT_RING_CAP)   // word w of entry e: ring[w * RT_RING_CAP + e]: origin, direction, lw, ray slot, instance + flags
+#define RT_PAIR_LIGHT_SHIFT 20            // = log2(RT_MAX_INSTANCES)
+#define RT_PAIR_SHADOW 0x10000000u
+#define RT_PAIR_DIRECTIONAL 0x20000000u
+
+struct PairRing { uint32_t* ring; uint32_t head, count; };
+
+__device__ __forceinline__ void ring_push(PairRing& R, bool want, const Ray& r, float lw, uint32_t gi, uint32_t ii, const RayRec& rr,
+                                          const ShadowSpec& ss, uint32_t lane) {
+    const unsigned long long mask = __ballot(want);
+    if (want) {
+        const uint32_t e = (R.head + R.count + __popcll(mask & ((1ull << lane) - 1ull))) & (RT_RING_CAP - 1);
+        uint32_t* q = R.ring + e;
+        q[0 * RT_RING_CAP] = __float_as_uint(r.o.x); q[1 * RT_RING_CAP] = __float_as_uint(r.o.y); q[2 * RT_RING_CAP] = __float_as_uint(r.o.z);
+        q[3 * RT_RING_CAP] = __float_as_uint(r.d.x); q[4 * RT_RING_CAP] = __float_as_uint(r.d.y); q[5 * RT_RING_CAP] = __float_as_uint(r.d.z);
+        q[6 * RT_RING_CAP] = __float_as_uint(lw);
+        q[7 * RT_RING_CAP] = gi;
+        q[8 * RT_RING_CAP] = ii | (ss.is_shadow ? (RT_PAIR_SHADOW | ((rr.meta & 0xFFu) << RT_PAIR_LIGHT_SHIFT)) : 0u) |
+                             (ss.directional ? RT_PAIR_DIRECTIONAL : 0u);
+    }
+    R.count += (uint32_t)__popcll(mask);
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Turns up to 64 waiting pairs into walk items.  Must be called by all lanes of the wave.
+__device__ __forceinline__ void ring_drain(PairRing& R, const DScene& S, const DFrame& F, uint32_t* out_n, uint32_t lane) {
+    const uint32_t n = R.count < RT_WAVE ? R.count : RT_WAVE;
+    bool pass = false;
+    float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
+    if (lane < n) {
+        const uint32_t* q = R.ring + ((R.head + lane) & (RT_RING_CAP - 1));
+        Ray r;
+        r.o = mk(__uint_as_float(q[0 * RT_RING_CAP]), __uint_as_float(q[1 * RT_RING_CAP]), __uint_as_float(q[2 * RT_RING_CAP]));
+        r.d = mk(__uint_as_float(q[3 * RT_RING_CAP]), __uint_as_float(q[4 * RT_RING_CAP]), __uint_as_float(q[5 * RT_RING_CAP]));
+        const float lw = __uint_as_float(q[6 * RT_RING_CAP]);
+        const uint32_t gi = q[7 * RT_RING_CAP], w = q[8 * RT_RING_CAP], ii = w & (RT_MAX_INSTANCES - 1u);
+        ShadowSpec ss;
+        ss.is_shadow = (w & RT_PAIR_SHADOW) != 0;
+        ss.directional = (w & RT_PAIR_DIRECTIONAL) != 0;
+        ss.limit_world = RT_INF;
+        if (ss.is_shadow && !ss.directional) ss.limit_world = distance3(r.o, ld3(S.lights[(w >> RT_PAIR_LIGHT_SHIFT) & 0xFFu].world));   // as shadow_spec
+        pass = walk_item(S.instances[ii], ii, gi, r, ss, lw, q0, q1, q2, q3);
+    }
+    __builtin_amdgcn_wave_barrier();
+    R.head = (R.head + n) & (RT_RING_CAP - 1);
+    R.count -= n;
+    const uint32_t slot = append_slot(pass, out_n, F.seg_fat, F.n_seg, F.fat_counts, F.ovf_fat, F.overflow, F.overflow_seq, lane);
+    if (slot != RT_REF_NONE) store_walk_item(F.fat_items, slot, q0, q1, q2, q3);
+}
+
 // Scene::intersect's three analytic groups (scene.rs:129-131 over intersect.rs:20-36): per group the closest
 // hit in Vec order, groups merged with the strict `<` of utils/mod.rs:17.  `settled`: a shadow ray that is
 // already known to be blocked needs nothing further (raytracer.rs:171-187).
@@ -694,6 +784,9 @@ extern "C" hipError_t rt_debug_setup_timing(unsigned long long* out, size_t n) {
 // enters within the distance that still matters.  Rays with a non-finite component are traced to the
 // end here, in the reference's exact order.
 // ======================================================================================================
+// five waves per SIMD (the list kernels run five blocks per compute unit): left to itself the compiler takes 113 registers,
+// four waves' worth, and the kernel, which mostly waits for memory, runs a third longer
+__attribute__((amdgpu_waves_per_eu(5)))
 __global__ void __launch_bounds__(RT_SETUP_THREADS) rt_setup(const DScene S, const DFrame F, const uint32_t level) {
     extern __shared__ uint32_t lds[];
     uint32_t* pre = lds;                       // n_seg + 1
@@ -738,6 +831,9 @@ __global__ void __launch_bounds__(RT_SETUP_THREADS) rt_setup(const DScene S, con
     const uint32_t lane = threadIdx.x & (RT_WAVE - 1);
     const uint32_t gwave = (blockIdx.x * blockDim.x + threadIdx.x) / RT_WAVE;
     const uint32_t n_waves = gridDim.x * (blockDim.x / RT_WAVE);
+    PairRing R;
+    R.ring = stage + stage_words + S.range_depth * blockDim.x + (threadIdx.x / RT_WAVE) * RT_RING_WORDS;
+    R.head = 0; R.count = 0;
 
     // Chunks of 64 rays: first the listed rays, then, light by light, the shadow rays of the hit records (a chunk
     // never mixes the two kinds, nor two lights).
@@ -799,84 +895,56 @@ __global__ void __launch_bounds__(RT_SETUP_THREADS) rt_setup(const DScene S, con
         const unsigned long long tc2 = clock64();
         ts[4] += tc2 - tc1;
 #endif
-        // mesh instances in Vec order (scene.rs:133-136): only decide whether the ray can touch the instance at all,
-        // within the distance that still matters; the local ray and the exact root test are rt_root's business
+        // mesh instances in Vec order (scene.rs:133-136): a world-space culling box decides whether the ray can touch the
+        // instance at all within the distance that still matters; the pairs that remain wait in the wave's ring for their
+        // local ray and the reference's root-box test (ring_drain)
         const V3 inv_w = mk(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
         float lw = ss.limit_world;
         if (have && best_t < lw) lw = best_t;
         const float lw_cut = lw * 1.000244140625f;
         if (S.n_range_nodes) {
-            // Many instances: each lane walks the range tree, left child first, so it meets its instances in Vec order.
+            // Many instances: each lane walks the range tree, left child first, so it meets its instances in Vec order; the
+            // wave steps through the walks together so that it can empty the ring in between
             uint32_t* walk = stage + stage_words + threadIdx.x;          // entry e of this lane: walk[e * blockDim.x]
             uint32_t sp = 0;
             if (active && !settled) { walk[0] = 0u; sp = 1; }
-            while (sp) {
-                const uint32_t k = walk[--sp * blockDim.x];
-                const float4 q0 = S.range_nodes[2 * k], q1 = S.range_nodes[2 * k + 1];
-                float tmin_w;
-                const bool pass = !(o_l1 < S.range_limits[k]) ||
-                                  (slab(q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, r.o, inv_w, tmin_w) && !(tmin_w > lw_cut));
-                if (!pass) continue;
-                const uint32_t left = __float_as_uint(q0.w);
-                if (left & 0x80000000u) {
-                    if (left == 0xFFFFFFFFu) continue;
-                    const uint32_t idx = atomicAdd(&out_n, 1u);
-                    uint32_t slot = RT_REF_NONE;
-                    if (idx < F.seg_items) slot = blockIdx.x * F.seg_items + idx;
-                    else {
-                        const uint32_t j = atomicAdd(&F.item_counts[F.n_seg - 1], 1u);      // the shared overflow segment
-                        if (j < F.ovf_items) slot = (F.n_seg - 1) * F.seg_items + j;
-                        else *F.overflow = F.overflow_seq;
+            while (__ballot(sp != 0)) {
+                bool want_item = false;
+                uint32_t ii = 0;
+                if (sp) {
+                    const uint32_t k = walk[--sp * blockDim.x];
+                    const float4 n0 = S.range_nodes[2 * k], n1 = S.range_nodes[2 * k + 1];
+                    float tmin_w;
+                    const bool pass = !(o_l1 < S.range_limits[k]) ||
+                                      (slab(n0.x, n0.y, n0.z, n1.x, n1.y, n1.z, r.o, inv_w, tmin_w) && !(tmin_w > lw_cut));
+                    const uint32_t left = __float_as_uint(n0.w);
+                    if (pass && (left & 0x80000000u)) {
+                        if (left != 0xFFFFFFFFu) { want_item = true; ii = left & 0x7FFFFFFFu; }
+                    } else if (pass) {
+                        walk[sp++ * blockDim.x] = __float_as_uint(n1.w);
+                        walk[sp++ * blockDim.x] = left;
                     }
-                    if (slot != RT_REF_NONE) F.items[slot] = make_uint2(gi, left & 0x7FFFFFFFu);
-                } else {
-                    walk[sp++ * blockDim.x] = __float_as_uint(q1.w);
-                    walk[sp++ * blockDim.x] = left;
+                }
+                if (__ballot(want_item)) {
+                    ring_push(R, want_item, r, lw, gi, ii, rr, ss, lane);
+                    if (R.count >= RT_WAVE) ring_drain(R, S, F, &out_n, lane);
                 }
             }
         }
-        // Otherwise eight instances at a time: all the tests first, then one reservation in this block's list segment
-        // for the whole group.  Within the group the pairs of instance k come before those of instance k + 1, so a
-        // ray's pairs keep the instances' Vec order.
-        const unsigned long long lanes_below = (1ull << lane) - 1ull;
-        for (uint32_t g0 = 0; g0 < (S.n_range_nodes ? 0u : S.n_instances); g0 += 8) {
-            unsigned long long wants[8];
-            uint32_t group_total = 0;
-#pragma unroll
-            for (uint32_t k = 0; k < 8; ++k) {
-                bool want_item = false;
-                if (g0 + k < S.n_instances) {
-                    const DInstance& inst = S.instances[g0 + k];
-                    if (active && !settled && inst.root_ref != RT_REF_NONE) {
-                        // the box is only trusted for origins within cull_origin_limit; farther rays always get a pair
-                        float tmin_w;
-                        want_item = !(o_l1 < inst.cull_origin_limit) ||
-                                    (slab(inst.world_lo[0], inst.world_lo[1], inst.world_lo[2], inst.world_hi[0], inst.world_hi[1],
-                                          inst.world_hi[2], r.o, inv_w, tmin_w) && !(tmin_w > lw_cut));
-                    }
-                }
-                wants[k] = __ballot(want_item);
-                group_total += __popcll(wants[k]);
+        // Otherwise instance by instance (the index is wave-uniform: the boxes come through scalar loads)
+        for (uint32_t ii = 0; ii < (S.n_range_nodes ? 0u : S.n_instances); ++ii) {
+            const DInstance& inst = S.instances[ii];
+            bool want_item = false;
+            if (active && !settled && inst.root_ref != RT_REF_NONE) {
+                // the box is only trusted for origins within cull_origin_limit; farther rays always get the exact test
+                float tmin_w;
+                want_item = !(o_l1 < inst.cull_origin_limit) ||
+                            (slab(inst.world_lo[0], inst.world_lo[1], inst.world_lo[2], inst.world_hi[0], inst.world_hi[1],
+                                  inst.world_hi[2], r.o, inv_w, tmin_w) && !(tmin_w > lw_cut));
             }
-            if (group_total == 0) continue;
-            uint32_t at = 0;
-            if (lane == 0) at = atomicAdd(&out_n, group_total);
-            at = __builtin_amdgcn_readfirstlane(at);
-#pragma unroll
-            for (uint32_t k = 0; k < 8; ++k) {
-                if ((wants[k] >> lane) & 1ull) {
-                    const uint32_t idx = at + __popcll(wants[k] & lanes_below);
-                    uint32_t slot = RT_REF_NONE;
-                    if (idx < F.seg_items) slot = blockIdx.x * F.seg_items + idx;
-                    else {
-                        const uint32_t j = atomicAdd(&F.item_counts[F.n_seg - 1], 1u);      // the shared overflow segment
-                        if (j < F.ovf_items) slot = (F.n_seg - 1) * F.seg_items + j;
-                        else *F.overflow = F.overflow_seq;
-                    }
-                    if (slot != RT_REF_NONE) F.items[slot] = make_uint2(gi, g0 + k);
-                }
-                at += __popcll(wants[k]);
-            }
+            if (!__ballot(want_item)) continue;
+            ring_push(R, want_item, r, lw, gi, ii, rr, ss, lane);
+            if (R.count >= RT_WAVE) ring_drain(R, S, F, &out_n, lane);
         }
 #ifdef RT_STATS
         const unsigned long long tc3 = clock64();
@@ -887,13 +955,14 @@ __global__ void __launch_bounds__(RT_SETUP_THREADS) rt_setup(const DScene S, con
         ts[6] += clock64() - tc3;
 #endif
     }
+    while (R.count) ring_drain(R, S, F, &out_n, lane);           // the pairs still waiting
 #ifdef RT_STATS
     ts[0] = clock64() - ts_begin;
     if (lane == 0 && gwave < 8192) for (int k = 0; k < 8; ++k) g_setup_timing[gwave * 8 + k] = ts[k];
 #endif
     __syncthreads();
     if (threadIdx.x == 0) {
-        F.item_counts[blockIdx.x] = out_n < F.seg_items ? out_n : F.seg_items;
+        F.fat_counts[blockIdx.x] = out_n < F.seg_fat ? out_n : F.seg_fat;
         F.slow_counts[blockIdx.x] = slow_n < F.seg_rays ? slow_n : F.seg_rays;
         if (slow_n) {
             F.slow_flags[level] = 1u;
@@ -914,7 +983,7 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_setup_slow(const DScene S
     uint32_t* pre = lds;                       // n_seg + 1
     uint32_t* scratch = lds + F.n_seg + 1;     // blockDim.x
     __shared__ uint32_t out_n;
-    if (threadIdx.x == 0) out_n = F.item_counts[blockIdx.x];        // this block's segment continues where rt_setup stopped
+    if (threadIdx.x == 0) out_n = F.fat_counts[blockIdx.x];         // this block's segment continues where rt_setup stopped
     const uint32_t n_rays = build_prefix(F.slow_counts, F.n_seg, F.seg_rays, F.ovf_rays, pre, scratch);
     // the analytic primitives are staged in LDS (every lane reads the same one: a broadcast, no scalar-load
     // round trip per primitive)
@@ -962,7 +1031,6 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_setup_slow(const DScene S
         }
 
         // mesh instances in Vec order (scene.rs:133-136)
-        const float o_l1 = fabsf(r.o.x) + fabsf(r.o.y) + fabsf(r.o.z);
         bool exact_mesh = false;             // exact path: the winner so far is a mesh triangle
         float ex_t = 0.0f, ex_u = 0.0f, ex_v = 0.0f; uint32_t ex_slot = 0, ex_inst = 0;
         // A candidate with t = NaN (a local ray with a NaN direction, as a singular instance matrix makes it) is only
@@ -1001,30 +1069,23 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_setup_slow(const DScene S
                         settled = early && have && (ss.directional || best_t < ss.limit_world);
                     }
                 } else {
-                    V3 inv = mk(1.0f / lr.d.x, 1.0f / lr.d.y, 1.0f / lr.d.z);
-                    float root_tmin;
-                    bool pass = slab(inst.root_lo[0], inst.root_lo[1], inst.root_lo[2], inst.root_hi[0], inst.root_hi[1],
-                                     inst.root_hi[2], lr.o, inv, root_tmin);
-                    if (pass && inst.prunable) {
-                        // beyond the best analytic hit (or the light) nothing in this mesh can matter; see rt_traverse
-                        float lw = ss.limit_world;
-                        if (have && best_t < lw) lw = best_t;
-                        if (lw < RT_INF) {
-                            float limit = (lw + 2.0f * inst.world_guard + 1.52587890625e-05f * (o_l1 + lw)) * dn * 1.0009765625f;
-                            pass = !(root_tmin > limit * RT_PRUNE_REL + inst.prune_abs);
-                        }
-                    }
-                    want_item = pass;
+                    want_item = true;
                 }
             }
-            uint32_t slot = append_slot(want_item, &out_n, F.seg_items, F.n_seg, F.item_counts, F.ovf_items, F.overflow, F.overflow_seq, lane);
-            if (slot != RT_REF_NONE) F.items[slot] = make_uint2(gi, ii);
+            // beyond the best analytic hit (or the light) nothing in this mesh can matter; see rt_traverse
+            float lw = ss.limit_world;
+            if (have && best_t < lw) lw = best_t;
+            float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
+            if (want_item) want_item = walk_item(inst, ii, gi, r, ss, lw, q0, q1, q2, q3);
+            const uint32_t slot = append_slot(want_item, &out_n, F.seg_fat, F.n_seg, F.fat_counts, F.ovf_fat, F.overflow, F.overflow_seq, lane);
+            if (slot != RT_REF_NONE) store_walk_item(F.fat_items, slot, q0, q1, q2, q3);
         }
         // a mesh winner found on the exact path is recorded as a finished work item
         {
-            uint32_t slot = append_slot(active && exact_mesh, &out_n, F.seg_items, F.n_seg, F.item_counts, F.ovf_items, F.overflow, F.overflow_seq, lane);
+            uint32_t slot = append_slot(active && exact_mesh, &out_n, F.seg_fat, F.n_seg, F.fat_counts, F.ovf_fat, F.overflow, F.overflow_seq, lane);
             if (slot != RT_REF_NONE) {
-                F.items[slot] = make_uint2(gi, ex_inst | RT_ITEM_DONE);
+                const float4 z = make_float4(0, 0, 0, 0);
+                store_walk_item(F.fat_items, slot, z, z, z, make_float4(__uint_as_float(gi), __uint_as_float(ex_inst | RT_FAT_DONE), 0.0f, 0.0f));
                 F.item_results[slot] = make_float4(ex_t, ex_u, ex_v, __uint_as_float(ex_slot));
                 best_order = RT_KEY_MESH | slot;
             } else if (active && exact_mesh) {
@@ -1038,74 +1099,6 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_setup_slow(const DScene S
             if (have) key = (ray_finite && !exact_mesh) ? make_key(best_t, best_order)
                                                         : (((unsigned long long)__float_as_uint(best_t) << 32) | best_order);
             F.best[gi] = key;
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) F.item_counts[blockIdx.x] = out_n < F.seg_items ? out_n : F.seg_items;
-}
-
-// ======================================================================================================
-// Kernel A2: per BVH work item, the mesh-local ray of intersect.rs:296-308 and the test of the mesh's root box
-// (the first iteration of intersect.rs:245-250).  Items that pass become 64-byte entries (see RT_FAT_FAST in
-// rt_device.h) the walk can start from with one fetch.
-// ======================================================================================================
-__global__ void __launch_bounds__(RT_ROOT_THREADS) rt_root(const DScene S, const DFrame F, const uint32_t level) {
-    extern __shared__ uint32_t lds[];
-    uint32_t* pre = lds;
-    uint32_t* scratch = lds + F.n_seg + 1;
-    __shared__ uint32_t out_n;
-    if (threadIdx.x == 0) out_n = 0;
-    const uint32_t n_items = build_prefix(F.item_counts, F.n_seg, F.seg_items, F.ovf_items, pre, scratch);
-    const uint32_t lane = threadIdx.x & (RT_WAVE - 1);
-    const uint32_t gwave = (blockIdx.x * blockDim.x + threadIdx.x) / RT_WAVE;
-    const uint32_t n_waves = gridDim.x * (blockDim.x / RT_WAVE);
-    for (uint32_t c = gwave; (unsigned long long)c * RT_WAVE < n_items; c += n_waves) {
-        const uint32_t v = c * RT_WAVE + lane;
-        bool pass = false;
-        float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
-        const uint32_t item = locate_chunk(pre, F.n_seg, F.seg_items, c * RT_WAVE, n_items, lane);
-        if (v < n_items) {
-            const uint2 it = F.items[item];
-            if (!(it.y & RT_ITEM_DONE)) {
-                const uint32_t gi = it.x, ii = it.y;
-                const RayRec rr = load_any_rec(S, F, level, gi);
-                const ShadowSpec ss = shadow_spec(S, rr);
-                const DInstance& inst = S.instances[ii];
-                const float o_l1 = fabsf(rr.ray.o.x) + fabsf(rr.ray.o.y) + fabsf(rr.ray.o.z);
-                Ray lr;
-                lr.o = transform34(inst.model_inverse, rr.ray.o);
-                V3 dv = transform34(inst.rotation_scale_inverse, rr.ray.d);
-                const float dn = sqrtf(dot3(dv, dv));
-                lr.d = mk(dv.x / dn, dv.y / dn, dv.z / dn);                 // glm::normalize, intersect.rs:304-308
-                const V3 inv = mk(1.0f / lr.d.x, 1.0f / lr.d.y, 1.0f / lr.d.z);
-                const bool fast = inst.prunable != 0;
-                const float slack_w = 2.0f * inst.world_guard;
-                // mesh-local bound on useful t: a hit at world distance w lies at local t = w * dn (up to world_guard)
-                float limit = RT_INF;
-                if (fast) {
-                    float lw = ss.limit_world;
-                    const unsigned long long key = F.best[gi];
-                    if (key != RT_KEY_NONE) { float bt = __uint_as_float((uint32_t)(key >> 32)); if (bt < lw) lw = bt; }
-                    if (lw < RT_INF) limit = (lw + slack_w + 1.52587890625e-05f * (o_l1 + lw)) * dn * 1.0009765625f;
-                }
-                float root_tmin;
-                pass = slab(inst.root_lo[0], inst.root_lo[1], inst.root_lo[2], inst.root_hi[0], inst.root_hi[1], inst.root_hi[2],
-                            lr.o, inv, root_tmin);
-                if (pass && fast && root_tmin > limit * RT_PRUNE_REL + inst.prune_abs) pass = false;
-                // Shadow rays: a candidate at local t lies within world_guard of world distance t / dn, and the pair's
-                // final hit is not farther than any candidate.
-                float thr = -RT_INF;
-                if (ss.is_shadow) thr = ss.directional ? RT_INF : ss.limit_world - (1.5f * slack_w + 6.103515625e-05f * (o_l1 + ss.limit_world));
-                q0 = make_float4(lr.o.x, lr.o.y, lr.o.z, root_tmin);
-                q1 = make_float4(lr.d.x, lr.d.y, lr.d.z, limit);
-                q2 = make_float4(1.0f / dn, thr, inst.prune_abs, __uint_as_float(inst.root_ref4));
-                q3 = make_float4(__uint_as_float(gi), __uint_as_float(ii | (fast ? RT_FAT_FAST : 0u)), __uint_as_float(item), 0.0f);
-            }
-        }
-        const uint32_t slot = append_slot(pass, &out_n, F.seg_fat, F.n_seg, F.fat_counts, F.ovf_fat, F.overflow, F.overflow_seq, lane);
-        if (slot != RT_REF_NONE) {
-            F.fat_items[4 * (size_t)slot] = q0; F.fat_items[4 * (size_t)slot + 1] = q1;
-            F.fat_items[4 * (size_t)slot + 2] = q2; F.fat_items[4 * (size_t)slot + 3] = q3;
         }
     }
     __syncthreads();
@@ -1274,9 +1267,9 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
                     limit = q1.w;
                     inv_dn = q2.x; shadow_thr = q2.y; prune_abs = q2.z;
                     gi = __float_as_uint(q3.x);
-                    ii = __float_as_uint(q3.y) & ~RT_FAT_FAST;
+                    ii = __float_as_uint(q3.y) & RT_FAT_INSTANCE;
                     fast = (__float_as_uint(q3.y) & RT_FAT_FAST) != 0;
-                    item = __float_as_uint(q3.z);
+                    item = (uint32_t)fat;
                     m_have = false; m_t = 0.0f; m_u = 0.0f; m_v = 0.0f; m_slot = 0;
                     cur_ref = __float_as_uint(q2.w);
                     cur_t = q0.w;
@@ -1374,7 +1367,7 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
                     }
                     if (improved) {
                         atomicMin((unsigned long long*)&recs[4 * owner], make_key(m_t, m_slot));
-                        // does this candidate already prove a shadow ray blocked (see rt_root)?
+                        // does this candidate already prove a shadow ray blocked (see walk_item)?
                         if (m_t * inv_dn < shadow_thr) {
                             sp = base;
                             cur_ref = RT_REF_NONE;
@@ -1537,7 +1530,7 @@ __global__ void __launch_bounds__(RT_SHADE_THREADS) rt_shade(const DScene S, con
     const uint32_t p = level & 1, q = p ^ 1;
     // the shared overflow segments of the work-item lists are done for this depth and start empty at the next
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        F.item_counts[F.n_seg - 1] = 0; F.fat_counts[F.n_seg - 1] = 0; F.slow_counts[F.n_seg - 1] = 0;
+        F.fat_counts[F.n_seg - 1] = 0; F.slow_counts[F.n_seg - 1] = 0;
     }
     const uint32_t n_rays = build_prefix(F.ray_counts[p], F.n_seg, F.seg_rays, F.ovf_rays, pre, scratch);
     const float4* rays = F.rays[p];
@@ -1593,7 +1586,7 @@ __global__ void __launch_bounds__(RT_SHADE_THREADS) rt_shade(const DScene S, con
                 if (order & RT_KEY_MESH) {
                     const uint32_t item = order & ~RT_KEY_MESH;
                     const float4 res = F.item_results[item];
-                    cl.inst = F.items[item].y & ~RT_ITEM_DONE;
+                    cl.inst = __float_as_uint(F.fat_items[4 * (size_t)item + 3].y) & RT_FAT_INSTANCE;
                     cl.tl = res.x; cl.u = res.y; cl.v = res.z; cl.slot = __float_as_uint(res.w);
                     cl.prim = ((uint32_t)RT_PRIM_MESH_TRIANGLE << 30) | __float_as_uint(S.tri_cold[3 * cl.slot].w);
                 } else {
@@ -1789,7 +1782,7 @@ extern "C" hipError_t rt_launch_generate(const DFrame* F, const DViews* V, uint3
 
 // One recursion depth: A, B, C and (from depth 1 on) D.  `blocks` is the grid of the list-producing
 // kernels (F->n_seg - 1), `traverse_blocks` that of the BVH walk.
-// `marks`, when not null, are five events recorded before A and after A', A2, B and C (kernel timing mode).
+// `marks`, when not null, are four events recorded before A and after A', B and C (kernel timing mode).
 extern "C" hipError_t rt_launch_level(const DScene* S, const DFrame* F, uint32_t level, uint32_t blocks,
                                       uint32_t traverse_blocks, hipStream_t stream, hipEvent_t* marks) {
     const size_t lds = list_lds_bytes(F->n_seg);
@@ -1799,7 +1792,8 @@ extern "C" hipError_t rt_launch_level(const DScene* S, const DFrame* F, uint32_t
 #endif
     if (marks) (void)hipEventRecord(marks[0], stream);
     hipLaunchKernelGGL(rt_setup, dim3(blocks), dim3(RT_SETUP_THREADS),
-                       lds + (F->n_seg + 1 + analytic_stage_words(*S) + (size_t)S->range_depth * RT_SETUP_THREADS) * sizeof(uint32_t),
+                       lds + (F->n_seg + 1 + analytic_stage_words(*S) + (size_t)S->range_depth * RT_SETUP_THREADS +
+                              (size_t)(RT_SETUP_THREADS / RT_WAVE) * RT_RING_WORDS) * sizeof(uint32_t),
                        stream, *S, *F, level);
     // In a scene whose instances all have culling boxes only stray rays (NaN components) reach this kernel, if any:
     // a small grid keeps the usual empty launch cheap.  (Block b continues list segment b, so any grid <= blocks works.)
@@ -1809,17 +1803,14 @@ extern "C" hipError_t rt_launch_level(const DScene* S, const DFrame* F, uint32_t
                            *S, *F, level);
     if (marks) (void)hipEventRecord(marks[1], stream);
     if (S->n_instances > 0)
-        hipLaunchKernelGGL(rt_root, dim3(blocks), dim3(RT_ROOT_THREADS), lds, stream, *S, *F, level);
-    if (marks) (void)hipEventRecord(marks[2], stream);
-    if (S->n_instances > 0)
         hipLaunchKernelGGL(rt_traverse, dim3(traverse_blocks), dim3(RT_BLOCK_THREADS), traverse_lds_bytes(F->n_seg, S->stack_lds),
                            stream, *S, *F, level);
 #ifdef RT_STATS
     if (stop && level == (uint32_t)atoi(stop)) return hipGetLastError();
 #endif
-    if (marks) (void)hipEventRecord(marks[3], stream);
+    if (marks) (void)hipEventRecord(marks[2], stream);
     hipLaunchKernelGGL(rt_shade, dim3(blocks), dim3(RT_SHADE_THREADS), lds, stream, *S, *F, level);
-    if (marks) (void)hipEventRecord(marks[4], stream);
+    if (marks) (void)hipEventRecord(marks[3], stream);
     return hipGetLastError();
 }
 

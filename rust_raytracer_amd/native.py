@@ -213,7 +213,7 @@ class DeviceScene:
         check(lib().rt_last_trace_ms(self._h, C.byref(ms)))
         return float(ms.value)
 
-    LEVEL_KERNELS = ("rt_setup", "rt_root", "rt_traverse", "rt_shade")
+    LEVEL_KERNELS = ("rt_setup", "rt_traverse", "rt_shade")
 
     def set_kernel_timing(self, enable: bool):
         check(lib().rt_set_kernel_timing(self._h, 1 if enable else 0))

@@ -524,7 +524,7 @@ def test_kernel_timing_mode(scenes_dir, model_dir):
         dev.close()
     assert np.array_equal(plain, timed)
     # depths 0..4 (the last one only holds the shadow rays of the deepest hits)
-    assert {n: c for n, (ms, c) in k.items()} == {"rt_setup": 5, "rt_root": 5, "rt_traverse": 5, "rt_shade": 5}
+    assert {n: c for n, (ms, c) in k.items()} == {"rt_setup": 5, "rt_traverse": 5, "rt_shade": 5}
     assert all(ms > 0.0 for ms, c in k.values())
     assert sum(ms for ms, c in k.values()) <= trace * 1.05
 
