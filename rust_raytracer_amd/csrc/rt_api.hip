@@ -635,7 +635,7 @@ static int carve_frame(uint32_t n_pixels, uint32_t n_lights, uint32_t blocks, ui
     sz->stats_words = (size_t)std::max<uint32_t>(blocks * 4, spill_lanes / 64) * 8;      // a row per wave of the largest grid
     // colour sums and poison words in one allocation, all counters in another: two clears per frame
     sz->pixel_clear_bytes = (size_t)3 * n_pixels * sizeof(long long) + (size_t)n_pixels * sizeof(unsigned int);
-    sz->counter_words = 6 * (size_t)f.n_seg + 2 * (RT_MAX_DEPTH_LIMIT + 2) + sz->stats_words;
+    sz->counter_words = 2 * (RT_MAX_DEPTH_LIMIT + 2) + sz->stats_words + (size_t)RT_COUNT_ROWS * (RT_MAX_DEPTH_LIMIT + 3) * f.n_seg;
     unsigned int* counters = nullptr;
     int rc;
     auto get = [&](size_t count, auto** p) {
@@ -647,20 +647,21 @@ static int carve_frame(uint32_t n_pixels, uint32_t n_lights, uint32_t blocks, ui
     if ((rc = get(sz->pixel_clear_bytes / sizeof(long long) + 1, &f.acc)) || (rc = get(sz->counter_words, &counters)) ||
         (rc = get((size_t)3 * n_pixels, &f.acc_big)) ||
         (rc = get(2 * ray_slots, &f.rays[0])) || (rc = get(2 * ray_slots, &f.rays[1])) ||      // shadow rays are not stored
-        (rc = get(all_ray_slots, &f.best)) ||
-        (rc = get(fat_slots, &f.item_results)) || (rc = get(4 * fat_slots, &f.fat_items)) || (rc = get(ray_slots, &f.slow_rays)) ||
+        (rc = get(all_ray_slots, &f.best[0])) || (rc = get(all_ray_slots, &f.best[1])) ||
+        (rc = get(fat_slots, &f.item_results[0])) || (rc = get(fat_slots, &f.item_results[1])) ||
+        (rc = get(4 * fat_slots, &f.fat_items[0])) || (rc = get(4 * fat_slots, &f.fat_items[1])) || (rc = get(ray_slots, &f.slow_rays)) ||
         (rc = get(3 * hit_slots, &f.hits[0])) || (rc = get(3 * hit_slots, &f.hits[1])))
         return rc;
     f.shadow_base = (uint32_t)ray_slots;
     f.spill_lanes = spill_lanes;
     if (spill_entries && (rc = get((size_t)spill_entries * spill_lanes, &f.spill))) return rc;
     unsigned int* c = counters;
-    f.ray_counts[0] = c; c += f.n_seg;   f.ray_counts[1] = c; c += f.n_seg;
-    f.fat_counts = c; c += f.n_seg;     f.slow_counts = c; c += f.n_seg;
-    f.hit_counts[0] = c; c += f.n_seg;   f.hit_counts[1] = c; c += f.n_seg;
+    // cleared per frame from the first word on: the per-depth counters, the statistics, then the count rows of the depths
+    // the frame can reach (enqueue_frame clears no further)
     f.chunk_counter = c; c += RT_MAX_DEPTH_LIMIT + 2;
     f.slow_flags = c; c += RT_MAX_DEPTH_LIMIT + 2;
-    f.wave_stats = c;
+    f.wave_stats = c; c += sz->stats_words;
+    f.counts = c;
     if (aux && ((rc = get((size_t)n_pixels, &f.aux_flags)) || (rc = get((size_t)n_pixels, &f.aux_prim)) ||
                 (rc = get((size_t)n_pixels, &f.aux_inst)) || (rc = get((size_t)n_pixels, &f.aux_t))))
         return rc;
@@ -821,14 +822,16 @@ static int enqueue_frame(RtScene* s, const RtRenderParams* p, bool sharded, bool
     if (!aux) { f.aux_flags = f.aux_prim = f.aux_inst = nullptr; f.aux_t = nullptr; }
     HIP_TRY(hipEventRecord(s->ev_start, stream));
     HIP_TRY(hipMemsetAsync(f.acc, 0, sz.pixel_clear_bytes, stream));                              // colour sums + poison words
-    HIP_TRY(hipMemsetAsync(f.ray_counts[0], 0, sz.counter_words * sizeof(unsigned int), stream));  // every counter + statistics
+    // a depth map only looks at the primary hits
+    const uint32_t last = p->mode == RT_MODE_DEPTH_MAP ? 0 : (s->d.n_lights > 0 ? max_depth : max_depth - 1);
+    // every counter, the statistics and the count rows of depths 0 .. last + 1
+    const size_t clear_words = 2 * (RT_MAX_DEPTH_LIMIT + 2) + sz.stats_words + (size_t)RT_COUNT_ROWS * (last + 2) * f.n_seg;
+    HIP_TRY(hipMemsetAsync(f.chunk_counter, 0, clear_words * sizeof(unsigned int), stream));
     // the scratch array keeps what the last call on this GPU left in it
     if (noalloc) HIP_TRY(hipMemsetAsync(f.acc_big, 0, (size_t)3 * g.n_pixels * sizeof(double), stream));
     if (aux) HIP_TRY(hipMemsetAsync(f.aux_flags, 0, (size_t)g.n_pixels * sizeof(unsigned int), stream));
     HIP_TRY(hipEventRecord(s->ev_trace_start, stream));
     HIP_TRY(rt_launch_generate(&f, &s->views, blocks, stream));
-    // a depth map only looks at the primary hits
-    const uint32_t last = p->mode == RT_MODE_DEPTH_MAP ? 0 : (s->d.n_lights > 0 ? max_depth : max_depth - 1);
     s->marked_levels = 0;
     if (s->kernel_timing && !noalloc) {
         while (s->marks.size() < (RT_N_LEVEL_KERNELS + 1) * (size_t)(last + 1)) {

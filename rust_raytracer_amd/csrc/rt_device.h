@@ -124,6 +124,13 @@ struct DScene {
 // The cameras of the views of a frame (rt_generate's own argument): column-major screen_to_world matrices.
 struct DViews { float m[RT_MAX_VIEWS][16]; };
 
+// Rows of DFrame::counts at depth d.
+#define RT_ROW_RAYS 0    // the rays traced at depth d (written by rt_generate, or by rt_shade at depth d - 1)
+#define RT_ROW_HITS 1    // the hit records of depth d - 1, whose shadow rays are traced at depth d
+#define RT_ROW_FAT 2     // the walk items of depth d
+#define RT_ROW_SLOW 3    // the rays of depth d left to rt_setup_slow
+#define RT_COUNT_ROWS 4
+
 // Per-frame device state.
 //
 // Work lists (rays, BVH work items, hit records) are cut into one segment per producer block plus
@@ -160,20 +167,20 @@ struct DFrame {
     // needed (shadow_rec in rt_kernels.hip), so the shadow rays of a depth cost no ray traffic at all.
     float4* rays[2];
     uint32_t shadow_base;
-    unsigned int* ray_counts[2];     // [n_seg]
-    unsigned long long* best;        // [ray slots] closest candidate so far: t bits << 32 | order, see rt_kernels.hip
-    float4* fat_items;               // walk items, 4 float4 per entry, segmented like the other lists
-    float4* item_results;            // per walk item: local t, u, v, bits triangle slot
-    unsigned int* fat_counts;        // [n_seg]
+    // Segment counts of the lists, one row of n_seg words per list and recursion depth, all zero when a frame starts (so
+    // no kernel ever has to reset one): the row of list k (RT_ROW_*) at depth d starts at counts[(4 * d + k) * n_seg].
+    // The data arrays behind them alternate between two copies with the depth's parity.
+    unsigned int* counts;
+    unsigned long long* best[2];     // [ray slots] closest candidate so far: t bits << 32 | order, see rt_kernels.hip
+    float4* fat_items[2];            // walk items, 4 float4 per entry, segmented like the other lists
+    float4* item_results[2];         // per walk item: local t, u, v, bits triangle slot
     unsigned int* slow_rays;         // ray slots rt_setup left to rt_setup_slow, segmented like the ray lists
-    unsigned int* slow_counts;       // [n_seg]
     unsigned int* slow_flags;        // [RT_MAX_DEPTH_LIMIT + 2] set when a depth has such rays
     uint2* spill;                    // traversal stack entries beyond DScene::stack_lds: entry e of walking lane g at [e * spill_lanes + g]
     uint32_t spill_lanes;            // lanes of the BVH walk's grid
     uint32_t walk_contiguous;        // the walk hands out runs of neighbouring pairs instead of interleaving them
     unsigned int* chunk_counter;     // [RT_MAX_DEPTH_LIMIT + 2] input chunks of the BVH walk handed out so far, per depth
     float4* hits[2];                 // Phong-shaded hits waiting for their shadow rays, 3 float4 each
-    unsigned int* hit_counts[2];     // [n_seg]
     unsigned int* wave_stats;        // [waves][8]: rays, primary, shadow, reflected, transmitted (rt_shade); 4-wide nodes visited, triangles tested (rt_traverse)
     // A list did not fit (the frame is then invalid): the kernels store the frame's sequence number here.  The host
     // only ever reads the word, so no report can be lost to a clear; frames of one handle run one after the other,

@@ -533,6 +533,33 @@ __device__ __forceinline__ uint32_t append_slot(bool want, uint32_t* lds_counter
     return RT_REF_NONE;
 }
 
+// The lists of one recursion depth (see DFrame::counts).
+struct LevelLists {
+    unsigned int* ray_counts;        // rays traced at this depth
+    unsigned int* hit_counts;        // hit records of the depth above
+    unsigned int* fat_counts;
+    unsigned int* slow_counts;
+    unsigned int* next_ray_counts;   // what rt_shade appends to at this depth
+    unsigned int* next_hit_counts;
+    unsigned long long* best;
+    float4* fat_items;
+    float4* item_results;
+};
+__device__ __forceinline__ LevelLists level_lists(const DFrame& F, uint32_t level) {
+    LevelLists L;
+    unsigned int* row = F.counts + (size_t)RT_COUNT_ROWS * level * F.n_seg;
+    L.ray_counts = row + RT_ROW_RAYS * F.n_seg;
+    L.hit_counts = row + RT_ROW_HITS * F.n_seg;
+    L.fat_counts = row + RT_ROW_FAT * F.n_seg;
+    L.slow_counts = row + RT_ROW_SLOW * F.n_seg;
+    L.next_ray_counts = L.ray_counts + RT_COUNT_ROWS * F.n_seg;
+    L.next_hit_counts = L.hit_counts + RT_COUNT_ROWS * F.n_seg;
+    L.best = F.best[level & 1];
+    L.fat_items = F.fat_items[level & 1];
+    L.item_results = F.item_results[level & 1];
+    return L;
+}
+
 // ---- exact walk for rays with a non-finite component ------------------------------------------------
 // intersect.rs:228-269 in the reference's own order, no pruning.  A candidate with t = NaN ends the walk:
 // nothing can replace it (utils/mod.rs:17).
@@ -662,7 +689,7 @@ __device__ __forceinline__ void ring_push(PairRing& R, bool want, const Ray& r, 
 }
 
 // Turns up to 64 waiting pairs into walk items.  Must be called by all lanes of the wave.
-__device__ __forceinline__ void ring_drain(PairRing& R, const DScene& S, const DFrame& F, uint32_t* out_n, uint32_t lane) {
+__device__ __forceinline__ void ring_drain(PairRing& R, const DScene& S, const DFrame& F, const LevelLists& L, uint32_t* out_n, uint32_t lane) {
     const uint32_t n = R.count < RT_WAVE ? R.count : RT_WAVE;
     bool pass = false;
     float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
@@ -683,8 +710,8 @@ __device__ __forceinline__ void ring_drain(PairRing& R, const DScene& S, const D
     __builtin_amdgcn_wave_barrier();
     R.head = (R.head + n) & (RT_RING_CAP - 1);
     R.count -= n;
-    const uint32_t slot = append_slot(pass, out_n, F.seg_fat, F.n_seg, F.fat_counts, F.ovf_fat, F.overflow, F.overflow_seq, lane);
-    if (slot != RT_REF_NONE) store_walk_item(F.fat_items, slot, q0, q1, q2, q3);
+    const uint32_t slot = append_slot(pass, out_n, F.seg_fat, F.n_seg, L.fat_counts, F.ovf_fat, F.overflow, F.overflow_seq, lane);
+    if (slot != RT_REF_NONE) store_walk_item(L.fat_items, slot, q0, q1, q2, q3);
 }
 
 // Scene::intersect's three analytic groups (scene.rs:129-131 over intersect.rs:20-36): per group the closest
@@ -758,11 +785,11 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_generate(const DFrame F, 
         if (inside) rr.ray = primary_ray(F, V.m[wave_view < F.n_views ? wave_view : 0], col, row);
         rr.throughput = 1.0f;
         rr.meta = p;
-        uint32_t slot = append_slot(inside, &out_n, F.seg_rays, F.n_seg, F.ray_counts[0], F.ovf_rays, F.overflow, F.overflow_seq, lane);
+        uint32_t slot = append_slot(inside, &out_n, F.seg_rays, F.n_seg, F.counts + RT_ROW_RAYS * F.n_seg, F.ovf_rays, F.overflow, F.overflow_seq, lane);
         if (slot != RT_REF_NONE) store_rec(F.rays[0], slot, rr);
     }
     __syncthreads();
-    if (threadIdx.x == 0) F.ray_counts[0][blockIdx.x] = out_n < F.seg_rays ? out_n : F.seg_rays;
+    if (threadIdx.x == 0) F.counts[RT_ROW_RAYS * F.n_seg + blockIdx.x] = out_n < F.seg_rays ? out_n : F.seg_rays;
 }
 
 #ifdef RT_STATS
@@ -788,6 +815,7 @@ extern "C" hipError_t rt_debug_setup_timing(unsigned long long* out, size_t n) {
 // four waves' worth, and the kernel, which mostly waits for memory, runs a third longer
 __attribute__((amdgpu_waves_per_eu(5)))
 __global__ void __launch_bounds__(RT_SETUP_THREADS) rt_setup(const DScene S, const DFrame F, const uint32_t level) {
+    const LevelLists L = level_lists(F, level);
     extern __shared__ uint32_t lds[];
     uint32_t* pre = lds;                       // n_seg + 1
     uint32_t* scratch = lds + F.n_seg + 1;     // blockDim.x
@@ -796,15 +824,14 @@ __global__ void __launch_bounds__(RT_SETUP_THREADS) rt_setup(const DScene S, con
     const uint32_t p = level & 1;
     // the shared overflow segments of the lists rt_shade fills at this depth start empty (nothing reads or
     // writes them before rt_shade)
-    if (blockIdx.x == 0 && threadIdx.x == 0) { F.ray_counts[p ^ 1][F.n_seg - 1] = 0; F.hit_counts[p][F.n_seg - 1] = 0; }
 #ifdef RT_STATS
     unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long ts_begin = clock64();
 #endif
-    const uint32_t n_rays = build_prefix(F.ray_counts[p], F.n_seg, F.seg_rays, F.ovf_rays, pre, scratch);
+    const uint32_t n_rays = build_prefix(L.ray_counts, F.n_seg, F.seg_rays, F.ovf_rays, pre, scratch);
     // second table: the hit records of the depth above, whose shadow rays are traced at this depth
     uint32_t* pre_hits = lds + F.n_seg + 1 + blockDim.x;
-    const uint32_t n_hits = build_prefix(F.hit_counts[p ^ 1], F.n_seg, F.seg_hits, F.ovf_hits, pre_hits, scratch);
+    const uint32_t n_hits = build_prefix(L.hit_counts, F.n_seg, F.seg_hits, F.ovf_hits, pre_hits, scratch);
     // the analytic primitives are staged in LDS (every lane reads the same one: a broadcast, no scalar-load
     // round trip per primitive)
     uint32_t* stage = pre_hits + F.n_seg + 1;
@@ -875,11 +902,11 @@ __global__ void __launch_bounds__(RT_SETUP_THREADS) rt_setup(const DScene S, con
         const bool easy = finite3(r.o) && finite3(r.d) && fabsf(r.d.x) + fabsf(r.d.y) + fabsf(r.d.z) < 4.0f &&
                           S.all_cullable != 0 && o_l1 < 1e15f;
         {
-            const uint32_t slot = append_slot(active && !easy, &slow_n, F.seg_rays, F.n_seg, F.slow_counts, F.ovf_rays, F.overflow, F.overflow_seq, lane);
+            const uint32_t slot = append_slot(active && !easy, &slow_n, F.seg_rays, F.n_seg, L.slow_counts, F.ovf_rays, F.overflow, F.overflow_seq, lane);
             if (slot != RT_REF_NONE) F.slow_rays[slot] = gi;
             // whatever happens to such a ray (rt_setup_slow may not be launched for this frame, its list may be full - either
             // way the frame is invalid), the later kernels must find a well-formed key
-            if (active && !easy) F.best[gi] = RT_KEY_NONE;
+            if (active && !easy) L.best[gi] = RT_KEY_NONE;
         }
         active = active && easy;
         const bool early = ss.is_shadow;
@@ -927,7 +954,7 @@ __global__ void __launch_bounds__(RT_SETUP_THREADS) rt_setup(const DScene S, con
                 }
                 if (__ballot(want_item)) {
                     ring_push(R, want_item, r, lw, gi, ii, rr, ss, lane);
-                    if (R.count >= RT_WAVE) ring_drain(R, S, F, &out_n, lane);
+                    if (R.count >= RT_WAVE) ring_drain(R, S, F, L, &out_n, lane);
                 }
             }
         }
@@ -944,26 +971,26 @@ __global__ void __launch_bounds__(RT_SETUP_THREADS) rt_setup(const DScene S, con
             }
             if (!__ballot(want_item)) continue;
             ring_push(R, want_item, r, lw, gi, ii, rr, ss, lane);
-            if (R.count >= RT_WAVE) ring_drain(R, S, F, &out_n, lane);
+            if (R.count >= RT_WAVE) ring_drain(R, S, F, L, &out_n, lane);
         }
 #ifdef RT_STATS
         const unsigned long long tc3 = clock64();
         ts[5] += tc3 - tc2;
 #endif
-        if (active) F.best[gi] = have ? make_key(best_t, best_order) : RT_KEY_NONE;
+        if (active) L.best[gi] = have ? make_key(best_t, best_order) : RT_KEY_NONE;
 #ifdef RT_STATS
         ts[6] += clock64() - tc3;
 #endif
     }
-    while (R.count) ring_drain(R, S, F, &out_n, lane);           // the pairs still waiting
+    while (R.count) ring_drain(R, S, F, L, &out_n, lane);           // the pairs still waiting
 #ifdef RT_STATS
     ts[0] = clock64() - ts_begin;
     if (lane == 0 && gwave < 8192) for (int k = 0; k < 8; ++k) g_setup_timing[gwave * 8 + k] = ts[k];
 #endif
     __syncthreads();
     if (threadIdx.x == 0) {
-        F.fat_counts[blockIdx.x] = out_n < F.seg_fat ? out_n : F.seg_fat;
-        F.slow_counts[blockIdx.x] = slow_n < F.seg_rays ? slow_n : F.seg_rays;
+        L.fat_counts[blockIdx.x] = out_n < F.seg_fat ? out_n : F.seg_fat;
+        L.slow_counts[blockIdx.x] = slow_n < F.seg_rays ? slow_n : F.seg_rays;
         if (slow_n) {
             F.slow_flags[level] = 1u;
             if (!F.slow_launched) *F.needs_slow = F.overflow_seq;      // nobody will trace these rays: the frame has to be redone
@@ -978,13 +1005,14 @@ __global__ void __launch_bounds__(RT_SETUP_THREADS) rt_setup(const DScene S, con
 // component) or the exact root test -> BVH work item.
 // ======================================================================================================
 __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_setup_slow(const DScene S, const DFrame F, const uint32_t level) {
+    const LevelLists L = level_lists(F, level);
     if (F.slow_flags[level] == 0) return;                          // the usual case: rt_setup kept every ray
     extern __shared__ uint32_t lds[];
     uint32_t* pre = lds;                       // n_seg + 1
     uint32_t* scratch = lds + F.n_seg + 1;     // blockDim.x
     __shared__ uint32_t out_n;
-    if (threadIdx.x == 0) out_n = F.fat_counts[blockIdx.x];         // this block's segment continues where rt_setup stopped
-    const uint32_t n_rays = build_prefix(F.slow_counts, F.n_seg, F.seg_rays, F.ovf_rays, pre, scratch);
+    if (threadIdx.x == 0) out_n = L.fat_counts[blockIdx.x];         // this block's segment continues where rt_setup stopped
+    const uint32_t n_rays = build_prefix(L.slow_counts, F.n_seg, F.seg_rays, F.ovf_rays, pre, scratch);
     // the analytic primitives are staged in LDS (every lane reads the same one: a broadcast, no scalar-load
     // round trip per primitive)
     uint32_t* stage = lds + F.n_seg + 1 + blockDim.x;
@@ -1077,16 +1105,16 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_setup_slow(const DScene S
             if (have && best_t < lw) lw = best_t;
             float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
             if (want_item) want_item = walk_item(inst, ii, gi, r, ss, lw, q0, q1, q2, q3);
-            const uint32_t slot = append_slot(want_item, &out_n, F.seg_fat, F.n_seg, F.fat_counts, F.ovf_fat, F.overflow, F.overflow_seq, lane);
-            if (slot != RT_REF_NONE) store_walk_item(F.fat_items, slot, q0, q1, q2, q3);
+            const uint32_t slot = append_slot(want_item, &out_n, F.seg_fat, F.n_seg, L.fat_counts, F.ovf_fat, F.overflow, F.overflow_seq, lane);
+            if (slot != RT_REF_NONE) store_walk_item(L.fat_items, slot, q0, q1, q2, q3);
         }
         // a mesh winner found on the exact path is recorded as a finished work item
         {
-            uint32_t slot = append_slot(active && exact_mesh, &out_n, F.seg_fat, F.n_seg, F.fat_counts, F.ovf_fat, F.overflow, F.overflow_seq, lane);
+            uint32_t slot = append_slot(active && exact_mesh, &out_n, F.seg_fat, F.n_seg, L.fat_counts, F.ovf_fat, F.overflow, F.overflow_seq, lane);
             if (slot != RT_REF_NONE) {
                 const float4 z = make_float4(0, 0, 0, 0);
-                store_walk_item(F.fat_items, slot, z, z, z, make_float4(__uint_as_float(gi), __uint_as_float(ex_inst | RT_FAT_DONE), 0.0f, 0.0f));
-                F.item_results[slot] = make_float4(ex_t, ex_u, ex_v, __uint_as_float(ex_slot));
+                store_walk_item(L.fat_items, slot, z, z, z, make_float4(__uint_as_float(gi), __uint_as_float(ex_inst | RT_FAT_DONE), 0.0f, 0.0f));
+                L.item_results[slot] = make_float4(ex_t, ex_u, ex_v, __uint_as_float(ex_slot));
                 best_order = RT_KEY_MESH | slot;
             } else if (active && exact_mesh) {
                 have = false;                                              // list overflow: the frame is redone anyway
@@ -1098,11 +1126,11 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_setup_slow(const DScene S
             unsigned long long key = RT_KEY_NONE;
             if (have) key = (ray_finite && !exact_mesh) ? make_key(best_t, best_order)
                                                         : (((unsigned long long)__float_as_uint(best_t) << 32) | best_order);
-            F.best[gi] = key;
+            L.best[gi] = key;
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) F.fat_counts[blockIdx.x] = out_n < F.seg_fat ? out_n : F.seg_fat;
+    if (threadIdx.x == 0) L.fat_counts[blockIdx.x] = out_n < F.seg_fat ? out_n : F.seg_fat;
 }
 
 // ======================================================================================================
@@ -1125,10 +1153,11 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_setup_slow(const DScene S
 // ======================================================================================================
 
 __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, const DFrame F, const uint32_t level) {
+    const LevelLists L = level_lists(F, level);
     extern __shared__ uint32_t lds[];
     uint32_t* pre = lds;
     uint32_t* scratch = lds + F.n_seg + 1;
-    const uint32_t n_items = build_prefix(F.fat_counts, F.n_seg, F.seg_fat, F.ovf_fat, pre, scratch);
+    const uint32_t n_items = build_prefix(L.fat_counts, F.n_seg, F.seg_fat, F.ovf_fat, pre, scratch);
     const uint32_t lane = threadIdx.x & (RT_WAVE - 1);
     const uint32_t wave = threadIdx.x / RT_WAVE;
     uint32_t* wave_stack = lds + F.n_seg + 1 + blockDim.x + wave * (2 * S.stack_lds * RT_WAVE);
@@ -1223,8 +1252,8 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
                             m_slot = win_slot;
                         }
                         float tw = world_t(S, S.instances[ii], lr, load_any_origin(S, F, level, gi), m_t, m_slot);      // from the ray's world origin
-                        F.item_results[item] = make_float4(m_t, m_u, m_v, __uint_as_float(m_slot));
-                        atomicMin(&F.best[gi], make_key(tw, RT_KEY_MESH | item));
+                        L.item_results[item] = make_float4(m_t, m_u, m_v, __uint_as_float(m_slot));
+                        atomicMin(&L.best[gi], make_key(tw, RT_KEY_MESH | item));
                     }
                 }
             }
@@ -1259,8 +1288,8 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
                     // different chunks.  A 64-byte item is a cache line of its own either way.
                     const size_t fat = locate(pre, F.n_seg, F.seg_fat, contiguous ? cur_chunk * chunk_len + chunk_next + rank
                                                                                 : cur_chunk + (chunk_next + rank) * n_chunks);
-                    const float4 q0 = F.fat_items[4 * fat], q1 = F.fat_items[4 * fat + 1], q2 = F.fat_items[4 * fat + 2],
-                                 q3 = F.fat_items[4 * fat + 3];
+                    const float4 q0 = L.fat_items[4 * fat], q1 = L.fat_items[4 * fat + 1], q2 = L.fat_items[4 * fat + 2],
+                                 q3 = L.fat_items[4 * fat + 3];
                     lr.o = mk(q0.x, q0.y, q0.z);
                     lr.d = mk(q1.x, q1.y, q1.z);
                     inv = mk(1.0f / lr.d.x, 1.0f / lr.d.y, 1.0f / lr.d.z);
@@ -1471,8 +1500,10 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
 // of the previous depth, now that their shadow rays have been traced.  Block-wide (it builds a prefix table).
 // ======================================================================================================
 __device__ void phong_pass(const DScene& S, const DFrame& F, const uint32_t level, uint32_t* pre, uint32_t* scratch) {
+    const unsigned int* hit_counts = level_lists(F, level).hit_counts;
+    const unsigned long long* shadow_keys = level_lists(F, level).best + F.shadow_base;      // see DFrame::rays
     const uint32_t q = (level & 1) ^ 1;            // parity of the depth whose hits are finished here
-    const uint32_t n_hits = build_prefix(F.hit_counts[q], F.n_seg, F.seg_hits, F.ovf_hits, pre, scratch);
+    const uint32_t n_hits = build_prefix(hit_counts, F.n_seg, F.seg_hits, F.ovf_hits, pre, scratch);
     const uint32_t lane = threadIdx.x & (RT_WAVE - 1);
     const uint32_t gwave = (blockIdx.x * blockDim.x + threadIdx.x) / RT_WAVE;
     const uint32_t n_waves = gridDim.x * (blockDim.x / RT_WAVE);
@@ -1492,7 +1523,7 @@ __device__ void phong_pass(const DScene& S, const DFrame& F, const uint32_t leve
             const DLight& L = S.lights[li];
             const bool directional = L.pos[3] == 0.0f;
             // trace_shadow_ray, raytracer.rs:171-187: any hit towards a directional light, a hit closer than a point light
-            const unsigned long long key = F.best[F.shadow_base + hs * S.n_lights + li];
+            const unsigned long long key = shadow_keys[hs * S.n_lights + li];
             const bool is_shadow = key != RT_KEY_NONE &&
                                    (directional || __uint_as_float((uint32_t)(key >> 32)) < distance3(position, ld3(L.world)));
             if (is_shadow && li < 4) shadow_bits |= RT_FLAG_SHADOW_LIGHT0 << li;
@@ -1522,17 +1553,14 @@ __device__ void phong_pass(const DScene& S, const DFrame& F, const uint32_t leve
 // worth; the list kernels run five blocks per compute unit
 __attribute__((amdgpu_waves_per_eu(5, 5)))
 __global__ void __launch_bounds__(RT_SHADE_THREADS) rt_shade(const DScene S, const DFrame F, const uint32_t level) {
+    const LevelLists L = level_lists(F, level);
     extern __shared__ uint32_t lds[];
     uint32_t* pre = lds;
     uint32_t* scratch = lds + F.n_seg + 1;
     __shared__ uint32_t out_rays, out_hits;
     if (threadIdx.x == 0) { out_rays = 0; out_hits = 0; }
     const uint32_t p = level & 1, q = p ^ 1;
-    // the shared overflow segments of the work-item lists are done for this depth and start empty at the next
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        F.fat_counts[F.n_seg - 1] = 0; F.slow_counts[F.n_seg - 1] = 0;
-    }
-    const uint32_t n_rays = build_prefix(F.ray_counts[p], F.n_seg, F.seg_rays, F.ovf_rays, pre, scratch);
+    const uint32_t n_rays = build_prefix(L.ray_counts, F.n_seg, F.seg_rays, F.ovf_rays, pre, scratch);
     const float4* rays = F.rays[p];
     float4* rays_out = F.rays[q];
     const uint32_t lane = threadIdx.x & (RT_WAVE - 1);
@@ -1551,7 +1579,7 @@ __global__ void __launch_bounds__(RT_SHADE_THREADS) rt_shade(const DScene S, con
         unsigned long long key = RT_KEY_NONE;
         {
             const uint32_t at = locate_chunk(pre, F.n_seg, F.seg_rays, c * RT_WAVE, n_rays, lane);
-            if (active) { gi = at; cur = load_rec(rays, gi); key = F.best[gi]; }
+            if (active) { gi = at; cur = load_rec(rays, gi); key = L.best[gi]; }
         }
         const bool have = key != RT_KEY_NONE;
         const float best_t = __uint_as_float((uint32_t)(key >> 32));
@@ -1585,8 +1613,8 @@ __global__ void __launch_bounds__(RT_SHADE_THREADS) rt_shade(const DScene S, con
                 cl.have = true; cl.t = best_t; cl.inst = RT_INSTANCE_NONE; cl.slot = 0; cl.tl = cl.u = cl.v = 0.0f;
                 if (order & RT_KEY_MESH) {
                     const uint32_t item = order & ~RT_KEY_MESH;
-                    const float4 res = F.item_results[item];
-                    cl.inst = __float_as_uint(F.fat_items[4 * (size_t)item + 3].y) & RT_FAT_INSTANCE;
+                    const float4 res = L.item_results[item];
+                    cl.inst = __float_as_uint(L.fat_items[4 * (size_t)item + 3].y) & RT_FAT_INSTANCE;
                     cl.tl = res.x; cl.u = res.y; cl.v = res.z; cl.slot = __float_as_uint(res.w);
                     cl.prim = ((uint32_t)RT_PRIM_MESH_TRIANGLE << 30) | __float_as_uint(S.tri_cold[3 * cl.slot].w);
                 } else {
@@ -1648,7 +1676,7 @@ __global__ void __launch_bounds__(RT_SHADE_THREADS) rt_shade(const DScene S, con
         }
 
         // ---- append: hit record, its shadow rays (one per light, raytracer.rs:77-79), child rays ----------
-        const uint32_t hit_slot = append_slot(emit_hit, &out_hits, F.seg_hits, F.n_seg, F.hit_counts[p], F.ovf_hits, F.overflow, F.overflow_seq, lane);
+        const uint32_t hit_slot = append_slot(emit_hit, &out_hits, F.seg_hits, F.n_seg, L.next_hit_counts, F.ovf_hits, F.overflow, F.overflow_seq, lane);
         if (hit_slot != RT_REF_NONE) {
             float4* H = F.hits[p] + 3 * (size_t)hit_slot;
             H[0] = make_float4(hit.position.x, hit.position.y, hit.position.z, __uint_as_float(hit.material));
@@ -1658,11 +1686,11 @@ __global__ void __launch_bounds__(RT_SHADE_THREADS) rt_shade(const DScene S, con
         // one shadow ray per light (raytracer.rs:77-79), traced at the next depth straight from the hit record (shadow_rec)
         if (hit_slot != RT_REF_NONE) n_shadow += S.n_lights;
         {
-            const uint32_t slot = append_slot(emit_r, &out_rays, F.seg_rays, F.n_seg, F.ray_counts[q], F.ovf_rays, F.overflow, F.overflow_seq, lane);
+            const uint32_t slot = append_slot(emit_r, &out_rays, F.seg_rays, F.n_seg, L.next_ray_counts, F.ovf_rays, F.overflow, F.overflow_seq, lane);
             if (slot != RT_REF_NONE) store_rec(rays_out, slot, rec_r);
         }
         {
-            const uint32_t slot = append_slot(emit_t, &out_rays, F.seg_rays, F.n_seg, F.ray_counts[q], F.ovf_rays, F.overflow, F.overflow_seq, lane);
+            const uint32_t slot = append_slot(emit_t, &out_rays, F.seg_rays, F.n_seg, L.next_ray_counts, F.ovf_rays, F.overflow, F.overflow_seq, lane);
             if (slot != RT_REF_NONE) store_rec(rays_out, slot, rec_t);
         }
     }
@@ -1678,8 +1706,8 @@ __global__ void __launch_bounds__(RT_SHADE_THREADS) rt_shade(const DScene S, con
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        F.ray_counts[q][blockIdx.x] = out_rays < F.seg_rays ? out_rays : F.seg_rays;
-        F.hit_counts[p][blockIdx.x] = out_hits < F.seg_hits ? out_hits : F.seg_hits;
+        L.next_ray_counts[blockIdx.x] = out_rays < F.seg_rays ? out_rays : F.seg_rays;
+        L.next_hit_counts[blockIdx.x] = out_hits < F.seg_hits ? out_hits : F.seg_hits;
     }
     // the hits of the depth above are complete now that this depth's rays - their shadow rays among them - are traced
     if (level > 0 && S.n_lights > 0) phong_pass(S, F, level, pre, scratch);
