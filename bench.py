@@ -66,16 +66,21 @@ def reference_walk_work(counters):
             "flops": FLOPS_PER_BOX_TEST * c["aabb_tests"] + FLOPS_PER_TRIANGLE_TEST * c["mesh_triangle_tests"]}
 
 
-def list_kernel_bytes(counts, n_lights):
+def list_kernel_bytes(counts, n_lights, setup_launches, levels):
     """Bytes the two list kernels have to move per frame (ray records 32 B, candidate keys 8 B, hit records 48 B, colour
-    sums 24 B), from the frame's ray counts: what each record costs once written and once read."""
+    sums 24 B), from the frame's ray counts: what each record costs once written and once read.  Shadow rays are not
+    stored: setting them up reads the 48-byte hit record once per light.  When rt_setup only ran at depth 0
+    (setup_launches < levels), rt_shade did the setting up of every later depth and is charged with it."""
     rays, primary, shadow, reflected, transmitted = (int(x) for x in counts[:5])
     listed = primary + reflected + transmitted          # rays of the segmented lists; the rest are shadow rays
     hits = shadow // max(n_lights, 1)
-    setup = rays * (32 + 8)                             # every ray read, its key written
-    shade = listed * (32 + 8) + hits * 48 + shadow * 32 + (reflected + transmitted) * 32 + listed * 24 \
+    setup_first = primary * (32 + 8)                                                # depth 0: every ray read, its key written
+    setup_later = (reflected + transmitted) * (32 + 8) + shadow * (48 + 8)
+    shade = listed * (32 + 8) + hits * 48 + (reflected + transmitted) * 32 + listed * 24 \
         + hits * (48 + 8 * n_lights + 24)               # ... and the Phong pass: hit record, shadow keys, colour sums
-    return {"rt_setup": setup, "rt_shade": shade}
+    if setup_launches < levels:
+        return {"rt_setup": setup_first, "rt_shade": shade + setup_later}
+    return {"rt_setup": setup_first + setup_later, "rt_shade": shade}
 
 
 def cpu_baseline(scene_path, model_dir, width, height, max_depth, budget_s=15.0):
@@ -428,7 +433,7 @@ def main():
                         "what": "bytes and flops of the reference's UN-PRUNED walk (oracle-counted) / this kernel's time: an equivalent "
                                 "rate, not work done and no roofline fraction"}
             else:
-                nbytes = list_kernel_bytes(frame_rays, n_lights)[dominant]
+                nbytes = list_kernel_bytes(frame_rays, n_lights, kernel_ms["rt_setup"][1], kernel_ms["rt_shade"][1])[dominant]
                 achieved = nbytes / per_frame_launches / seconds / 1e9
                 roofline.update({"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                  "work": {"bytes_per_frame": nbytes, "bytes_per_ray": nbytes / max(rays_per_frame, 1),

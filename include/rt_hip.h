@@ -262,7 +262,7 @@ int rt_render_device(RtScene* scene, const RtRenderParams* params, void* d_out);
  * candidate keys, BVH work items, hit records, colour sums, counters) are carved out of one static array in device
  * memory that the library holds on every GPU it runs on (rt_noalloc_scratch_bytes: 128 MiB) instead of the handle's
  * own buffers, and the call performs no hipMalloc / hipFree, whatever the frame size or the handle's history.
- * Limits: the frame's buffers must fit the array - about 2.6 KB per local pixel (views x this shard's tiles) in a scene
+ * Limits: the frame's buffers must fit the array - about 2.3 KB per local pixel (views x this shard's tiles) in a scene
  * with two lights, i.e. frames up to roughly 256x192; larger ones fail with RT_ERR_OUT_OF_RANGE and a message that
  * names both sizes (use rt_render_device for them).  The lists hold eight rays per pixel and recursion depth and
  * cannot grow: if a frame needs more, rt_last_ray_counts reports the overflow as it does after rt_render_device.

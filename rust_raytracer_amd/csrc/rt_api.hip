@@ -18,7 +18,7 @@
 
 extern "C" {
 hipError_t rt_launch_generate(const DFrame* F, const DViews* V, uint32_t blocks, hipStream_t stream);
-hipError_t rt_launch_level(const DScene* S, const DFrame* F, uint32_t level, uint32_t blocks, uint32_t traverse_blocks,
+hipError_t rt_launch_level(const DScene* S, const DFrame* F, uint32_t level, uint32_t last, uint32_t blocks, uint32_t traverse_blocks,
                            hipStream_t stream, hipEvent_t* marks);      // launches rt_setup_slow iff F->slow_launched
 hipError_t rt_launch_resolve(const DFrame* F, uint8_t* out, uint32_t bytes_per_pixel, uint32_t tiled, hipStream_t stream);
 hipError_t rt_launch_resolve_aux(const DFrame* F, uint32_t* prim, uint32_t* inst, uint8_t* flags, float* hit_t, hipStream_t stream);
@@ -57,6 +57,8 @@ struct RtScene {
     hipStream_t last_stream = nullptr;
     int n_cus = 0;
     uint32_t list_blocks = 0;           // grid of the list-producing kernels
+    uint32_t fuse_setup = 1;            // DFrame::fuse_setup (RT_FUSE_SETUP overrides the choice made at creation)
+    bool last_fused = false;            // ... as the frame enqueued last had it
     uint32_t traverse_blocks = 0;       // grid of the BVH walk
     // Host-mapped word into which the kernels store the sequence number of a frame whose lists did not fit.  The host
     // never writes it: what it has seen so far is `overflow_seen`, what it has not yet told the caller `overflow_unreported`.
@@ -505,6 +507,7 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device_id, RtScene**
         }
     }
     s->d.n_range_nodes = (uint32_t)range_limits.size();
+    s->d.n_tri_slots = (uint32_t)(hot.size() / 3);
     s->d.range_depth = range_depth;
     s->d.all_cullable = 1;
     for (const DInstance& di : instances) {
@@ -520,6 +523,11 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device_id, RtScene**
     // five blocks per compute unit for the list kernels (measured on the 1080p bunnies frame: 4: 3.02 ms, 5: 2.93 ms,
     // 6: 2.94 ms with rt_shade squeezed into 80 registers, 8: 3.6 ms)
     s->list_blocks = (uint32_t)s->n_cus * 5;
+    // rt_shade sets up the rays it makes, block by block - unless the scene has so many instances that rays walk the range
+    // tree: what a ray costs then varies too much for a block to be left alone with its own rays (measured: the 2.6 M- and
+    // 10.5 M-triangle grids lose 2-3 %, every other workload gains 2-9 % per frame)
+    s->fuse_setup = s->d.n_range_nodes == 0 ? 1u : 0u;
+    if (const char* env = getenv("RT_FUSE_SETUP")) s->fuse_setup = atoi(env) ? 1u : 0u;
     if (const char* env = getenv("RT_LIST_BLOCKS_PER_CU")) { int v = atoi(env); if (v >= 1 && v <= 8) s->list_blocks = (uint32_t)(s->n_cus * v); }
     int bpc = rt_query_traverse_blocks_per_cu(s->list_blocks + 1, s->d.stack_lds);
     if (bpc < 1) return bail(fail(RT_ERR_DEVICE, "the traversal kernel does not fit a compute unit"));
@@ -653,6 +661,7 @@ static int carve_frame(uint32_t n_pixels, uint32_t n_lights, uint32_t blocks, ui
         (rc = get(3 * hit_slots, &f.hits[0])) || (rc = get(3 * hit_slots, &f.hits[1])))
         return rc;
     f.shadow_base = (uint32_t)ray_slots;
+    f.n_fat_slots = (uint32_t)fat_slots;
     f.spill_lanes = spill_lanes;
     if (spill_entries && (rc = get((size_t)spill_entries * spill_lanes, &f.spill))) return rc;
     unsigned int* c = counters;
@@ -681,6 +690,7 @@ static void fill_frame(const RtScene* s, const Geometry& g, uint32_t max_depth, 
     f->needs_slow = s->d_overflow + 1;
     f->slow_launched = s->slow_enabled ? 1u : 0u;
     f->walk_contiguous = s->walk_contiguous;
+    f->fuse_setup = s->fuse_setup;
 }
 
 static int ensure_frame(RtScene* s, const Geometry& g, uint32_t max_depth, bool aux) {
@@ -842,13 +852,14 @@ static int enqueue_frame(RtScene* s, const RtRenderParams* p, bool sharded, bool
         s->marked_levels = last + 1;
     }
     for (uint32_t level = 0; level <= last; ++level)
-        HIP_TRY(rt_launch_level(&s->d, &f, level, blocks, s->traverse_blocks, stream,
+        HIP_TRY(rt_launch_level(&s->d, &f, level, last, blocks, s->traverse_blocks, stream,
                                 s->marked_levels ? &s->marks[(RT_N_LEVEL_KERNELS + 1) * (size_t)level] : nullptr));
     HIP_TRY(hipEventRecord(s->ev_trace_stop, stream));
     HIP_TRY(rt_launch_resolve(&f, d_out, bytes_per_pixel(p->output_format), g.shard_count > 1 ? 1u : 0u, stream));
     HIP_TRY(hipEventRecord(s->ev_stop, stream));
     s->timed = true;
     s->last_f = f;
+    s->last_fused = f.fuse_setup != 0;
     s->last_stats_words = sz.stats_words;
     return RT_OK;
 }
@@ -1020,7 +1031,7 @@ extern "C" int rt_last_kernel_ms(RtScene* s, float out_ms[RT_N_LEVEL_KERNELS], u
     for (uint32_t level = 0; level < s->marked_levels; ++level) {
         const hipEvent_t* m = &s->marks[(RT_N_LEVEL_KERNELS + 1) * (size_t)level];
         for (int k = 0; k < RT_N_LEVEL_KERNELS; ++k) {
-            const bool launched = k == RT_KERNEL_SETUP || k == RT_KERNEL_SHADE ||
+            const bool launched = (k == RT_KERNEL_SETUP && (level == 0 || !s->last_fused)) || k == RT_KERNEL_SHADE ||
                                   (k == RT_KERNEL_TRAVERSE && s->d.n_instances > 0);
             if (!launched) continue;
             float ms = 0.0f;

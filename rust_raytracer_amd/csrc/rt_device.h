@@ -87,6 +87,7 @@ struct DInstance {
 struct DScene {
     RtBackground background;
     uint32_t n_lights, n_planes, n_spheres, n_triangles, n_instances;
+    uint32_t n_tri_slots;        // entries of tri_hot / tri_cold
     uint32_t stack_entries;      // per-lane traversal stack entries a walk of any mesh's 4-wide tree can need
     uint32_t stack_lds;          // how many of them live in LDS (the rest, rarely reached, in DFrame::spill)
     uint32_t all_cullable;       // every instance has a usable culling box (DInstance::cullable)
@@ -152,6 +153,7 @@ struct DFrame {
     uint32_t n_seg;                  // producer blocks + 1 (the last segment is the shared overflow segment)
     uint32_t seg_rays, ovf_rays;     // capacity of a block's ray segment / of the overflow segment
     uint32_t seg_fat, ovf_fat;       // (ray, instance) pairs that pass the exact root-box test: the walk items
+    uint32_t n_fat_slots;            // entries of fat_items / item_results
     uint32_t seg_hits, ovf_hits;
     long long* acc;                  // [3][n_pixels] fixed-point colour sums, 2^-40 units
     double* acc_big;                 // [3][n_pixels] sums of the rare contributions beyond 2^22
@@ -179,6 +181,7 @@ struct DFrame {
     uint2* spill;                    // traversal stack entries beyond DScene::stack_lds: entry e of walking lane g at [e * spill_lanes + g]
     uint32_t spill_lanes;            // lanes of the BVH walk's grid
     uint32_t walk_contiguous;        // the walk hands out runs of neighbouring pairs instead of interleaving them
+    uint32_t fuse_setup;             // rt_shade sets up the rays it makes (rt_setup only runs at depth 0)
     unsigned int* chunk_counter;     // [RT_MAX_DEPTH_LIMIT + 2] input chunks of the BVH walk handed out so far, per depth
     float4* hits[2];                 // Phong-shaded hits waiting for their shadow rays, 3 float4 each
     unsigned int* wave_stats;        // [waves][8]: rays, primary, shadow, reflected, transmitted (rt_shade); 4-wide nodes visited, triangles tested (rt_traverse)

@@ -796,105 +796,105 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_generate(const DFrame F, 
 // Diagnostic build: per wave of the last rt_traverse launch: cycles, rounds, refill cycles, refills, cycles and
 // count of rounds in which some lane tested a leaf, cycles and count of the other rounds, sum of walking lanes.
 __device__ unsigned long long g_wave_timing[8192 * 10];
-__device__ unsigned long long g_setup_timing[8192 * 8];
 extern "C" hipError_t rt_debug_wave_timing(unsigned long long* out, size_t n) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_timing), n * sizeof(unsigned long long));
-}
-extern "C" hipError_t rt_debug_setup_timing(unsigned long long* out, size_t n) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_setup_timing), n * sizeof(unsigned long long));
 }
 #endif
 
 // ======================================================================================================
 // Kernel A: per ray, the analytic primitives (scene.rs:129-131) and the root test of every mesh instance.
-// Writes the best analytic candidate to F.best and one BVH work item per instance whose root box the ray
-// enters within the distance that still matters.  Rays with a non-finite component are traced to the
-// end here, in the reference's exact order.
+// Writes the best analytic candidate to `best` and one walk item per instance whose root box the ray
+// enters within the distance that still matters.  Rays with a non-finite component go to rt_setup_slow.
+// The work runs either as a kernel of its own over all the rays of a depth (rt_setup) or, block by block,
+// at the end of rt_shade over the rays that block has just made (see there).
 // ======================================================================================================
-// five waves per SIMD (the list kernels run five blocks per compute unit): left to itself the compiler takes 113 registers,
-// four waves' worth, and the kernel, which mostly waits for memory, runs a third longer
-__attribute__((amdgpu_waves_per_eu(5)))
-__global__ void __launch_bounds__(RT_SETUP_THREADS) rt_setup(const DScene S, const DFrame F, const uint32_t level) {
+
+// Copies the analytic primitives into LDS (every lane reads the same one: a broadcast, no scalar-load round trip per
+// primitive).  Block-wide.
+__device__ __forceinline__ void stage_analytic(const DScene& S, uint32_t* stage) {
+    const uint32_t stage_words = analytic_stage_words(S);
+    if (!stage_words) return;
+    const uint32_t plane_words = S.n_planes * (sizeof(DPlane) / 4), sphere_words = S.n_spheres * (sizeof(DSphere) / 4);
+    for (uint32_t w = threadIdx.x; w < stage_words; w += blockDim.x) {
+        uint32_t v;
+        if (w < plane_words) v = ((const uint32_t*)S.planes)[w];
+        else if (w < plane_words + sphere_words) v = ((const uint32_t*)S.spheres)[w - plane_words];
+        else v = ((const uint32_t*)S.triangles)[w - plane_words - sphere_words];
+        stage[w] = v;
+    }
+    __syncthreads();
+}
+
+// LDS words behind the staged primitives: the range-tree stacks of the block's lanes and the rings of its waves.
+__device__ __host__ inline size_t setup_work_words(uint32_t range_depth, uint32_t threads) {
+    return (size_t)range_depth * threads + (size_t)(threads / RT_WAVE) * RT_RING_WORDS;
+}
+
+// Where a block finds the rays it sets up.
+struct SetupInput {
+    // rt_setup: all segments of the depth's lists, through prefix tables in LDS
+    const uint32_t* pre; const uint32_t* pre_hits;
+    uint32_t n_rays, n_hits;
+    // rt_shade: what this block has just appended - the first own_* entries of its own segments and the slots it took from
+    // the shared overflow segments (n_rays = own_rays + number of extra_rays, likewise for the hit records)
+    uint32_t own_rays, own_hits;
+    const uint32_t* extra_rays; const uint32_t* extra_hits;
+};
+
+// `stage`: the staged primitives (stage_analytic), followed by setup_work_words() of scratch.  `out_n`, `slow_n`: the block's
+// LDS counters of walk items and of rays left to rt_setup_slow.  LOCAL: see SetupInput.
+template <bool LOCAL>
+__device__ __forceinline__ void setup_rays(const DScene& S, const DFrame& F, const uint32_t level, const SetupInput& in,
+                                           uint32_t* stage, uint32_t* out_n_ptr, uint32_t* slow_n_ptr) {
     const LevelLists L = level_lists(F, level);
-    extern __shared__ uint32_t lds[];
-    uint32_t* pre = lds;                       // n_seg + 1
-    uint32_t* scratch = lds + F.n_seg + 1;     // blockDim.x
-    __shared__ uint32_t out_n, slow_n;
-    if (threadIdx.x == 0) { out_n = 0; slow_n = 0; }
     const uint32_t p = level & 1;
-    // the shared overflow segments of the lists rt_shade fills at this depth start empty (nothing reads or
-    // writes them before rt_shade)
-#ifdef RT_STATS
-    unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const unsigned long long ts_begin = clock64();
-#endif
-    const uint32_t n_rays = build_prefix(L.ray_counts, F.n_seg, F.seg_rays, F.ovf_rays, pre, scratch);
-    // second table: the hit records of the depth above, whose shadow rays are traced at this depth
-    uint32_t* pre_hits = lds + F.n_seg + 1 + blockDim.x;
-    const uint32_t n_hits = build_prefix(L.hit_counts, F.n_seg, F.seg_hits, F.ovf_hits, pre_hits, scratch);
-    // the analytic primitives are staged in LDS (every lane reads the same one: a broadcast, no scalar-load
-    // round trip per primitive)
-    uint32_t* stage = pre_hits + F.n_seg + 1;
     const uint32_t stage_words = analytic_stage_words(S);
     const bool staged = stage_words != 0;
     const uint32_t plane_words = S.n_planes * (sizeof(DPlane) / 4), sphere_words = S.n_spheres * (sizeof(DSphere) / 4);
     const DPlane* ld_planes = (const DPlane*)stage;
     const DSphere* ld_spheres = (const DSphere*)(stage + plane_words);
     const DTriangle* ld_triangles = (const DTriangle*)(stage + plane_words + sphere_words);
-    if (staged) {
-        for (uint32_t w = threadIdx.x; w < stage_words; w += blockDim.x) {
-            uint32_t v;
-            if (w < plane_words) v = ((const uint32_t*)S.planes)[w];
-            else if (w < plane_words + sphere_words) v = ((const uint32_t*)S.spheres)[w - plane_words];
-            else v = ((const uint32_t*)S.triangles)[w - plane_words - sphere_words];
-            stage[w] = v;
-        }
-        __syncthreads();
-    }
-#ifdef RT_STATS
-    ts[1] = clock64() - ts_begin;
-#endif
     const float4* rays = F.rays[p];
     const uint32_t lane = threadIdx.x & (RT_WAVE - 1);
-    const uint32_t gwave = (blockIdx.x * blockDim.x + threadIdx.x) / RT_WAVE;
-    const uint32_t n_waves = gridDim.x * (blockDim.x / RT_WAVE);
+    // the waves that share the input: all of the grid, or those of the block
+    const uint32_t my_wave = LOCAL ? threadIdx.x / RT_WAVE : (blockIdx.x * blockDim.x + threadIdx.x) / RT_WAVE;
+    const uint32_t n_waves = LOCAL ? blockDim.x / RT_WAVE : gridDim.x * (blockDim.x / RT_WAVE);
     PairRing R;
     R.ring = stage + stage_words + S.range_depth * blockDim.x + (threadIdx.x / RT_WAVE) * RT_RING_WORDS;
     R.head = 0; R.count = 0;
+    uint32_t& out_n = *out_n_ptr;
+    uint32_t& slow_n = *slow_n_ptr;
 
     // Chunks of 64 rays: first the listed rays, then, light by light, the shadow rays of the hit records (a chunk
     // never mixes the two kinds, nor two lights).
-    const uint32_t main_chunks = (n_rays + RT_WAVE - 1) / RT_WAVE, hit_chunks = (n_hits + RT_WAVE - 1) / RT_WAVE;
+    const uint32_t main_chunks = (in.n_rays + RT_WAVE - 1) / RT_WAVE, hit_chunks = (in.n_hits + RT_WAVE - 1) / RT_WAVE;
     const uint32_t all_chunks = main_chunks + S.n_lights * hit_chunks;
-    for (uint32_t c = gwave; c < all_chunks; c += n_waves) {
+    for (uint32_t c = my_wave; c < all_chunks; c += n_waves) {
         bool active;
         uint32_t gi = 0;
         RayRec rr;
         rr.ray.o = rr.ray.d = mk(0, 0, 0);
         rr.throughput = 0.0f;
         rr.meta = 0;
-#ifdef RT_STATS
-        const unsigned long long tc0 = clock64();
-        ts[2] += 1;
-#endif
         if (c < main_chunks) {
-            const uint32_t at = locate_chunk(pre, F.n_seg, F.seg_rays, c * RT_WAVE, n_rays, lane);
-            active = c * RT_WAVE + lane < n_rays;
+            const uint32_t v = c * RT_WAVE + lane;
+            active = v < in.n_rays;
+            uint32_t at;
+            if (LOCAL) at = v < in.own_rays ? blockIdx.x * F.seg_rays + v : (active ? in.extra_rays[v - in.own_rays] : 0u);
+            else at = locate_chunk(in.pre, F.n_seg, F.seg_rays, c * RT_WAVE, in.n_rays, lane);
             if (active) gi = at;
         } else {
             const uint32_t cs = c - main_chunks, light = cs / hit_chunks, first = (cs - light * hit_chunks) * RT_WAVE;
-            const uint32_t hs = locate_chunk(pre_hits, F.n_seg, F.seg_hits, first, n_hits, lane);
-            active = first + lane < n_hits;
+            const uint32_t v = first + lane;
+            active = v < in.n_hits;
+            uint32_t hs;
+            if (LOCAL) hs = v < in.own_hits ? blockIdx.x * F.seg_hits + v : (active ? in.extra_hits[v - in.own_hits] : 0u);
+            else hs = locate_chunk(in.pre_hits, F.n_seg, F.seg_hits, first, in.n_hits, lane);
             if (active) { gi = F.shadow_base + hs * S.n_lights + light; rr = shadow_rec(S, F.hits[p ^ 1], hs, light); }
         }
         if (active && c < main_chunks) rr = load_rec(rays, gi);
         const Ray r = rr.ray;
         const ShadowSpec ss = shadow_spec(S, rr);
-#ifdef RT_STATS
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        const unsigned long long tc1 = clock64();
-        ts[3] += tc1 - tc0;
-#endif
         // Rays this kernel does not handle go to rt_setup_slow: non-finite components (the reference's exact order
         // matters for them), directions far from unit length or origins so far out that a local ray could
         // overflow (instance matrices of a cullable scene are below 1e15), or an instance without a culling box.
@@ -918,10 +918,6 @@ __global__ void __launch_bounds__(RT_SETUP_THREADS) rt_setup(const DScene S, con
             if (staged) analytic_hits(S, ld_planes, ld_spheres, ld_triangles, r, early, ss, have, best_t, best_order, settled);
             else analytic_hits(S, S.planes, S.spheres, S.triangles, r, early, ss, have, best_t, best_order, settled);
         }
-#ifdef RT_STATS
-        const unsigned long long tc2 = clock64();
-        ts[4] += tc2 - tc1;
-#endif
         // mesh instances in Vec order (scene.rs:133-136): a world-space culling box decides whether the ray can touch the
         // instance at all within the distance that still matters; the pairs that remain wait in the wave's ring for their
         // local ray and the reference's root-box test (ring_drain)
@@ -973,20 +969,9 @@ __global__ void __launch_bounds__(RT_SETUP_THREADS) rt_setup(const DScene S, con
             ring_push(R, want_item, r, lw, gi, ii, rr, ss, lane);
             if (R.count >= RT_WAVE) ring_drain(R, S, F, L, &out_n, lane);
         }
-#ifdef RT_STATS
-        const unsigned long long tc3 = clock64();
-        ts[5] += tc3 - tc2;
-#endif
         if (active) L.best[gi] = have ? make_key(best_t, best_order) : RT_KEY_NONE;
-#ifdef RT_STATS
-        ts[6] += clock64() - tc3;
-#endif
     }
     while (R.count) ring_drain(R, S, F, L, &out_n, lane);           // the pairs still waiting
-#ifdef RT_STATS
-    ts[0] = clock64() - ts_begin;
-    if (lane == 0 && gwave < 8192) for (int k = 0; k < 8; ++k) g_setup_timing[gwave * 8 + k] = ts[k];
-#endif
     __syncthreads();
     if (threadIdx.x == 0) {
         L.fat_counts[blockIdx.x] = out_n < F.seg_fat ? out_n : F.seg_fat;
@@ -996,6 +981,27 @@ __global__ void __launch_bounds__(RT_SETUP_THREADS) rt_setup(const DScene S, con
             if (!F.slow_launched) *F.needs_slow = F.overflow_seq;      // nobody will trace these rays: the frame has to be redone
         }
     }
+}
+
+// five waves per SIMD (the list kernels run five blocks per compute unit): left to itself the compiler takes 113 registers,
+// four waves' worth, and the kernel, which mostly waits for memory, runs a third longer
+__attribute__((amdgpu_waves_per_eu(5)))
+__global__ void __launch_bounds__(RT_SETUP_THREADS) rt_setup(const DScene S, const DFrame F, const uint32_t level) {
+    const LevelLists L = level_lists(F, level);
+    extern __shared__ uint32_t lds[];
+    uint32_t* pre = lds;                                   // n_seg + 1
+    uint32_t* scratch = lds + F.n_seg + 1;                 // blockDim.x
+    uint32_t* pre_hits = scratch + blockDim.x;             // n_seg + 1: the hit records of the depth above, whose shadow rays are traced at this depth
+    uint32_t* stage = pre_hits + F.n_seg + 1;
+    __shared__ uint32_t out_n, slow_n;
+    if (threadIdx.x == 0) { out_n = 0; slow_n = 0; }
+    SetupInput in;
+    in.pre = pre; in.pre_hits = pre_hits;
+    in.n_rays = build_prefix(L.ray_counts, F.n_seg, F.seg_rays, F.ovf_rays, pre, scratch);
+    in.n_hits = build_prefix(L.hit_counts, F.n_seg, F.seg_hits, F.ovf_hits, pre_hits, scratch);
+    in.own_rays = in.own_hits = 0; in.extra_rays = in.extra_hits = nullptr;
+    stage_analytic(S, stage);
+    setup_rays<false>(S, F, level, in, stage, &out_n, &slow_n);
 }
 
 // ======================================================================================================
@@ -1499,6 +1505,22 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
 // Second half of kernel C: the Phong sum of shade_phong / radiance (raytracer.rs:75-84, 137-153) for the hits
 // of the previous depth, now that their shadow rays have been traced.  Block-wide (it builds a prefix table).
 // ======================================================================================================
+// rt_shade with setup_next: a slot in a shared overflow segment is not in the block's own segment, so the block keeps a
+// list of those it took (few, if any).  A block that takes more than the list holds spoils the frame, which is then redone
+// with longer lists, like any frame whose lists were too short.
+#define RT_LOCAL_EXTRA_RAYS 512     // (what the four waves of a block can emit from one chunk of rays each)
+#define RT_LOCAL_EXTRA_HITS 256
+// Its entry stays in the list, though, and nobody sets it up: its `keys_per_slot` keys (the key of a ray; the keys of the
+// shadow rays of a hit record) are written here, so that the next depth finds well-formed ones.
+__device__ __forceinline__ void note_extra(const DFrame& F, uint32_t slot, uint32_t seg_cap, uint32_t* list, uint32_t list_len, uint32_t* n,
+                                           unsigned long long* keys, uint32_t keys_per_slot) {
+    if (slot == RT_REF_NONE || slot < (F.n_seg - 1) * seg_cap) return;
+    const uint32_t k = atomicAdd(n, 1u);
+    if (k < list_len) { list[k] = slot; return; }
+    *F.overflow = F.overflow_seq;
+    for (uint32_t j = 0; j < keys_per_slot; ++j) keys[(size_t)slot * keys_per_slot + j] = RT_KEY_NONE;
+}
+
 __device__ void phong_pass(const DScene& S, const DFrame& F, const uint32_t level, uint32_t* pre, uint32_t* scratch) {
     const unsigned int* hit_counts = level_lists(F, level).hit_counts;
     const unsigned long long* shadow_keys = level_lists(F, level).best + F.shadow_base;      // see DFrame::rays
@@ -1552,14 +1574,18 @@ __device__ void phong_pass(const DScene& S, const DFrame& F, const uint32_t leve
 // five waves per SIMD: the kernel needs 97 registers, which the allocation granule would round up to four waves'
 // worth; the list kernels run five blocks per compute unit
 __attribute__((amdgpu_waves_per_eu(5, 5)))
-__global__ void __launch_bounds__(RT_SHADE_THREADS) rt_shade(const DScene S, const DFrame F, const uint32_t level) {
+__global__ void __launch_bounds__(RT_SHADE_THREADS) rt_shade(const DScene S, const DFrame F, const uint32_t level, const uint32_t setup_next) {
     const LevelLists L = level_lists(F, level);
     extern __shared__ uint32_t lds[];
     uint32_t* pre = lds;
     uint32_t* scratch = lds + F.n_seg + 1;
-    __shared__ uint32_t out_rays, out_hits;
-    if (threadIdx.x == 0) { out_rays = 0; out_hits = 0; }
+    // only with setup_next: the slots this block takes from the shared overflow segments, then what setup_rays needs
+    uint32_t* extra_rays = lds + F.n_seg + 1 + RT_MAX_LIST_THREADS;
+    uint32_t* extra_hits = extra_rays + RT_LOCAL_EXTRA_RAYS;
+    __shared__ uint32_t out_rays, out_hits, n_extra_rays, n_extra_hits, fat_n, slow_n;
+    if (threadIdx.x == 0) { out_rays = 0; out_hits = 0; n_extra_rays = 0; n_extra_hits = 0; fat_n = 0; slow_n = 0; }
     const uint32_t p = level & 1, q = p ^ 1;
+    unsigned long long* next_best = F.best[q];
     const uint32_t n_rays = build_prefix(L.ray_counts, F.n_seg, F.seg_rays, F.ovf_rays, pre, scratch);
     const float4* rays = F.rays[p];
     float4* rays_out = F.rays[q];
@@ -1581,9 +1607,14 @@ __global__ void __launch_bounds__(RT_SHADE_THREADS) rt_shade(const DScene S, con
             const uint32_t at = locate_chunk(pre, F.n_seg, F.seg_rays, c * RT_WAVE, n_rays, lane);
             if (active) { gi = at; cur = load_rec(rays, gi); key = L.best[gi]; }
         }
-        const bool have = key != RT_KEY_NONE;
         const float best_t = __uint_as_float((uint32_t)(key >> 32));
         const uint32_t order = (uint32_t)key;
+        // A frame whose lists overflowed (it is invalid and will be redone) may hold keys nobody wrote: a key that names no
+        // walk item or primitive counts as a miss, so that every index stays inside its array.
+        bool have = key != RT_KEY_NONE;
+        if (order & RT_KEY_MESH) have = have && (order & ~RT_KEY_MESH) < F.n_fat_slots;
+        else have = have && (order & 0x1FFFFFFFu) < ((order >> 29) == RT_PRIM_PLANE ? S.n_planes : (order >> 29) == RT_PRIM_SPHERE ? S.n_spheres :
+                                                    (order >> 29) == RT_PRIM_TRIANGLE ? S.n_triangles : 0u);
 
         bool emit_r = false, emit_t = false, emit_hit = false;
         RayRec rec_r, rec_t;
@@ -1613,8 +1644,10 @@ __global__ void __launch_bounds__(RT_SHADE_THREADS) rt_shade(const DScene S, con
                 cl.have = true; cl.t = best_t; cl.inst = RT_INSTANCE_NONE; cl.slot = 0; cl.tl = cl.u = cl.v = 0.0f;
                 if (order & RT_KEY_MESH) {
                     const uint32_t item = order & ~RT_KEY_MESH;
-                    const float4 res = L.item_results[item];
+                    float4 res = L.item_results[item];
                     cl.inst = __float_as_uint(L.fat_items[4 * (size_t)item + 3].y) & RT_FAT_INSTANCE;
+                    if (__float_as_uint(res.w) >= S.n_tri_slots) res.w = 0.0f;         // (stale results of such a frame, see above)
+                    if (cl.inst >= S.n_instances) cl.inst = 0;
                     cl.tl = res.x; cl.u = res.y; cl.v = res.z; cl.slot = __float_as_uint(res.w);
                     cl.prim = ((uint32_t)RT_PRIM_MESH_TRIANGLE << 30) | __float_as_uint(S.tri_cold[3 * cl.slot].w);
                 } else {
@@ -1677,6 +1710,7 @@ __global__ void __launch_bounds__(RT_SHADE_THREADS) rt_shade(const DScene S, con
 
         // ---- append: hit record, its shadow rays (one per light, raytracer.rs:77-79), child rays ----------
         const uint32_t hit_slot = append_slot(emit_hit, &out_hits, F.seg_hits, F.n_seg, L.next_hit_counts, F.ovf_hits, F.overflow, F.overflow_seq, lane);
+        if (setup_next) note_extra(F, hit_slot, F.seg_hits, extra_hits, RT_LOCAL_EXTRA_HITS, &n_extra_hits, next_best + F.shadow_base, S.n_lights);
         if (hit_slot != RT_REF_NONE) {
             float4* H = F.hits[p] + 3 * (size_t)hit_slot;
             H[0] = make_float4(hit.position.x, hit.position.y, hit.position.z, __uint_as_float(hit.material));
@@ -1687,10 +1721,12 @@ __global__ void __launch_bounds__(RT_SHADE_THREADS) rt_shade(const DScene S, con
         if (hit_slot != RT_REF_NONE) n_shadow += S.n_lights;
         {
             const uint32_t slot = append_slot(emit_r, &out_rays, F.seg_rays, F.n_seg, L.next_ray_counts, F.ovf_rays, F.overflow, F.overflow_seq, lane);
+            if (setup_next) note_extra(F, slot, F.seg_rays, extra_rays, RT_LOCAL_EXTRA_RAYS, &n_extra_rays, next_best, 1);
             if (slot != RT_REF_NONE) store_rec(rays_out, slot, rec_r);
         }
         {
             const uint32_t slot = append_slot(emit_t, &out_rays, F.seg_rays, F.n_seg, L.next_ray_counts, F.ovf_rays, F.overflow, F.overflow_seq, lane);
+            if (setup_next) note_extra(F, slot, F.seg_rays, extra_rays, RT_LOCAL_EXTRA_RAYS, &n_extra_rays, next_best, 1);
             if (slot != RT_REF_NONE) store_rec(rays_out, slot, rec_t);
         }
     }
@@ -1711,6 +1747,25 @@ __global__ void __launch_bounds__(RT_SHADE_THREADS) rt_shade(const DScene S, con
     }
     // the hits of the depth above are complete now that this depth's rays - their shadow rays among them - are traced
     if (level > 0 && S.n_lights > 0) phong_pass(S, F, level, pre, scratch);
+    // ---- the next depth's rt_setup, block by block: the rays and hit records this block has just appended are all it needs,
+    // and a block is the only writer of its segments, so no other block has to be waited for
+    if (setup_next) {
+        // The block's own stores to device memory have to be done before its other waves load them.  A fence of workgroup
+        // scope waits for exactly that (__syncthreads alone only orders LDS); a device-wide __threadfence() would write back
+        // and invalidate the whole L2 of the XCD, about 100 us per launch.
+        __threadfence_block();
+        __syncthreads();
+        SetupInput in;
+        in.pre = in.pre_hits = nullptr;
+        in.own_rays = out_rays < F.seg_rays ? out_rays : F.seg_rays;
+        in.own_hits = out_hits < F.seg_hits ? out_hits : F.seg_hits;
+        in.extra_rays = extra_rays; in.extra_hits = extra_hits;
+        in.n_rays = in.own_rays + (n_extra_rays < RT_LOCAL_EXTRA_RAYS ? n_extra_rays : RT_LOCAL_EXTRA_RAYS);
+        in.n_hits = in.own_hits + (n_extra_hits < RT_LOCAL_EXTRA_HITS ? n_extra_hits : RT_LOCAL_EXTRA_HITS);
+        uint32_t* stage = extra_hits + RT_LOCAL_EXTRA_HITS;
+        stage_analytic(S, stage);
+        setup_rays<true>(S, F, level + 1, in, stage, &fat_n, &slow_n);
+    }
 }
 
 // color.rs:42-52 + canvas layout.  One thread per local pixel.
@@ -1811,7 +1866,9 @@ extern "C" hipError_t rt_launch_generate(const DFrame* F, const DViews* V, uint3
 // One recursion depth: A, B, C and (from depth 1 on) D.  `blocks` is the grid of the list-producing
 // kernels (F->n_seg - 1), `traverse_blocks` that of the BVH walk.
 // `marks`, when not null, are four events recorded before A and after A', B and C (kernel timing mode).
-extern "C" hipError_t rt_launch_level(const DScene* S, const DFrame* F, uint32_t level, uint32_t blocks,
+// With F->fuse_setup, rt_shade also does the next depth's rt_setup (every depth but `last`), and rt_setup itself is only
+// launched at depth 0.
+extern "C" hipError_t rt_launch_level(const DScene* S, const DFrame* F, uint32_t level, uint32_t last, uint32_t blocks,
                                       uint32_t traverse_blocks, hipStream_t stream, hipEvent_t* marks) {
     const size_t lds = list_lds_bytes(F->n_seg);
 #ifdef RT_STATS
@@ -1819,10 +1876,10 @@ extern "C" hipError_t rt_launch_level(const DScene* S, const DFrame* F, uint32_t
     if (stop && level > (uint32_t)atoi(stop)) return hipSuccess;
 #endif
     if (marks) (void)hipEventRecord(marks[0], stream);
-    hipLaunchKernelGGL(rt_setup, dim3(blocks), dim3(RT_SETUP_THREADS),
-                       lds + (F->n_seg + 1 + analytic_stage_words(*S) + (size_t)S->range_depth * RT_SETUP_THREADS +
-                              (size_t)(RT_SETUP_THREADS / RT_WAVE) * RT_RING_WORDS) * sizeof(uint32_t),
-                       stream, *S, *F, level);
+    const size_t setup_words = analytic_stage_words(*S) + setup_work_words(S->range_depth, RT_SETUP_THREADS);
+    if (level == 0 || !F->fuse_setup)
+        hipLaunchKernelGGL(rt_setup, dim3(blocks), dim3(RT_SETUP_THREADS),
+                           lds + (F->n_seg + 1 + setup_words) * sizeof(uint32_t), stream, *S, *F, level);
     // In a scene whose instances all have culling boxes only stray rays (NaN components) reach this kernel, if any:
     // a small grid keeps the usual empty launch cheap.  (Block b continues list segment b, so any grid <= blocks works.)
     const uint32_t slow_blocks = (S->all_cullable && blocks > 64) ? 64 : blocks;
@@ -1837,7 +1894,9 @@ extern "C" hipError_t rt_launch_level(const DScene* S, const DFrame* F, uint32_t
     if (stop && level == (uint32_t)atoi(stop)) return hipGetLastError();
 #endif
     if (marks) (void)hipEventRecord(marks[2], stream);
-    hipLaunchKernelGGL(rt_shade, dim3(blocks), dim3(RT_SHADE_THREADS), lds, stream, *S, *F, level);
+    const uint32_t setup_next = (F->fuse_setup && level < last) ? 1u : 0u;
+    hipLaunchKernelGGL(rt_shade, dim3(blocks), dim3(RT_SHADE_THREADS),
+                       lds + (setup_next ? (RT_LOCAL_EXTRA_RAYS + RT_LOCAL_EXTRA_HITS + setup_words) * sizeof(uint32_t) : 0), stream, *S, *F, level, setup_next);
     if (marks) (void)hipEventRecord(marks[3], stream);
     return hipGetLastError();
 }

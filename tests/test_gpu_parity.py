@@ -523,8 +523,9 @@ def test_kernel_timing_mode(scenes_dir, model_dir):
     finally:
         dev.close()
     assert np.array_equal(plain, timed)
-    # depths 0..4 (the last one only holds the shadow rays of the deepest hits)
-    assert {n: c for n, (ms, c) in k.items()} == {"rt_setup": 5, "rt_traverse": 5, "rt_shade": 5}
+    # depths 0..4 (the last one only holds the shadow rays of the deepest hits); after depth 0 rt_shade sets up the rays
+    # it makes itself (scenes with few instances), so rt_setup runs once
+    assert {n: c for n, (ms, c) in k.items()} == {"rt_setup": 1, "rt_traverse": 5, "rt_shade": 5}
     assert all(ms > 0.0 for ms, c in k.values())
     assert sum(ms for ms, c in k.values()) <= trace * 1.05
 
