@@ -1296,6 +1296,8 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
                                                                                 : cur_chunk + (chunk_next + rank) * n_chunks);
                     const float4 q0 = L.fat_items[4 * fat], q1 = L.fat_items[4 * fat + 1], q2 = L.fat_items[4 * fat + 2],
                                  q3 = L.fat_items[4 * fat + 3];
+                    // (an entry of a ray traced on the exact path only records a result, see rt_setup_slow: there is nothing to walk)
+                    if (!(__float_as_uint(q3.y) & RT_FAT_DONE)) {
                     lr.o = mk(q0.x, q0.y, q0.z);
                     lr.d = mk(q1.x, q1.y, q1.z);
                     inv = mk(1.0f / lr.d.x, 1.0f / lr.d.y, 1.0f / lr.d.z);
@@ -1317,6 +1319,7 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
                     recs[4 * lane] = 0xFFFFFFFFu; recs[4 * lane + 1] = 0xFFFFFFFFu;
                     recs[4 * lane + 2] = 1u; recs[4 * lane + 3] = 0u;
                     running = true;
+                    }
                 }
             }
             chunk_next += asking < avail ? asking : avail;
