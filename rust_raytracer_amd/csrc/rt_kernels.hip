@@ -1335,6 +1335,7 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
                     donor_list[give_rank] = lane;
                     atomicAdd(&recs[4 * owner + 2], 1u);
                 }
+                __builtin_amdgcn_wave_barrier();                               // the takers read what the givers have just written
                 uint32_t src = lane;
                 if (taking) src = donor_list[idle_rank];
                 const float ox = __shfl(lr.o.x, src), oy = __shfl(lr.o.y, src), oz = __shfl(lr.o.z, src);
