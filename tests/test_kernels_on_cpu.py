@@ -1,0 +1,93 @@
+"""The library's own kernels, compiled for the host and run on the CPU under AddressSanitizer (tests/emu), against the
+oracle.  This is test infrastructure, not a fallback: the emulation lives under tests/, nothing in the package can load it,
+and the library proper still refuses to run without a GPU (tests/test_host_loader.py).  What it buys: the kernels' list
+bookkeeping, the BVH walk and the exact path are checked for out-of-bounds accesses and for parity on every CPU run - a
+memory fault on the GPU takes the whole box down and names no line, here it stops at the line.
+
+Blocks run one after the other, the threads of a block are fibers that meet at __syncthreads and at the wave collectives;
+device memory is malloc.  The emulated device has two compute units (ten list segments), so frames are kept tiny."""
+import json
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import orc
+from rust_raytracer_amd import synthetic
+
+EMU = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu")
+
+
+@pytest.fixture(scope="module")
+def emu_render():
+    if shutil.which("g++") is None or shutil.which("make") is None:
+        pytest.skip("no g++ / make")
+    probe = subprocess.run("echo 'int main(){return 0;}' | g++ -fsanitize=address -x c++ - -o /dev/null", shell=True, capture_output=True)
+    if probe.returncode != 0:
+        pytest.skip("g++ has no AddressSanitizer runtime here")
+    r = subprocess.run(["make", "-C", EMU, "emu_render"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return os.path.join(EMU, "emu_render")
+
+
+def render_and_compare(emu_render, scene_text, model_dir, work, max_depth, queue_capacity=0):
+    path = os.path.join(work, "scene.json")
+    with open(path, "w") as f:
+        f.write(scene_text)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
+    if queue_capacity:
+        env["EMU_QUEUE_CAPACITY"] = str(queue_capacity)
+    out = os.path.join(work, "out")
+    r = subprocess.run([emu_render, model_dir, str(max_depth), path, out], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-4000:]                       # a sanitizer report ends up here
+    s = orc.OracleScene.from_text(scene_text, model_dir)
+    try:
+        want = s.render(max_depth=max_depth)
+    finally:
+        s.close()
+    h, w = want["rgb"].shape[:2]
+    assert np.array_equal(np.fromfile(out + ".prim", dtype=np.uint32).reshape(h, w), want["prim_id"])
+    assert np.array_equal(np.fromfile(out + ".inst", dtype=np.uint32).reshape(h, w), want["instance_id"])
+    assert np.array_equal(np.fromfile(out + ".flags", dtype=np.uint8).reshape(h, w), want["flags"])
+    assert np.array_equal(np.fromfile(out + ".t", dtype=np.float32).reshape(h, w), want["hit_t"], equal_nan=True)
+    assert np.fromfile(out + ".counters", dtype=np.uint64)[:5].tolist() == [int(x) for x in want["counters"][:5]]
+    diff = np.abs(np.fromfile(out + ".rgb", dtype=np.uint8).reshape(h, w, 3).astype(int) - want["rgb"].astype(int)).max(axis=2)
+    assert (diff <= 1).mean() >= 0.98, (diff <= 1).mean()
+    return int(want["counters"][0])
+
+
+def small(scenes_dir, name, width, height):
+    scene = json.load(open(os.path.join(scenes_dir, name + ".json")))
+    scene["camera"]["screen_dimensions"] = [width, height]
+    return json.dumps(scene)
+
+
+def test_reference_scenes(emu_render, scenes_dir, model_dir, tmp_path):
+    """No meshes (rt_setup as a phase of rt_shade, the Phong pass) and the headline scene (instances, the 4-wide walk with
+    subtree sharing, reflection and refraction), the second one also with ray lists far too short for the frame."""
+    for k, (name, w, h, depth, capacity) in enumerate([("cornell_box", 96, 64, 5, 0), ("reflective_bunnies", 72, 40, 5, 0),
+                                                        ("reflective_bunnies", 72, 40, 4, 900)]):
+        work = tmp_path / str(k)
+        work.mkdir()
+        rays = render_and_compare(emu_render, small(scenes_dir, name, w, h), model_dir, str(work), depth, capacity)
+        assert rays > w * h
+
+
+def test_generated_scenes(emu_render, tmp_path):
+    """Random scenes (every primitive kind and material) and scenes spoiled on purpose: singular instance matrices put rays
+    on the exact path (rt_setup_slow, entries that only record a result), duplicates make ties."""
+    d = str(tmp_path)
+    seen = set()
+    for seed in (3, 11):
+        work = tmp_path / ("random%d" % seed)
+        work.mkdir()
+        render_and_compare(emu_render, synthetic.random_scene(d, seed, 64, 40), d, str(work), 4)
+    for seed in range(60000, 60006):
+        text, what = synthetic.spoiled_scene(d, seed, 64, 40)
+        seen.update(what)
+        work = tmp_path / ("spoiled%d" % seed)
+        work.mkdir()
+        render_and_compare(emu_render, text, d, str(work), 4)
+    assert "zero scale" in seen or "duplicate instance" in seen, seen
