@@ -21,9 +21,3 @@ for level in (0, 1, 2, 5, 9):
     print('level', level, 'waves', len(tm), 'cycles mean %.0f max %.0f rounds mean %.1f max %.0f lanes/round %.1f' % (tm[:, 0].mean(), tm[:, 0].max(), tm[:, 1].mean(), tm[:, 1].max(), tm[:, 8].sum() / tm[:, 1].sum()))
     print('   service %.1f%% of wave time; leaf rounds %.0f%% of rounds, %.1f lanes and %.0f cycles per leaf round (%.1f%% of wave time)' % (
         100 * tm[:, 9].sum() / tot, 100 * tm[:, 5].sum() / tm[:, 1].sum(), tm[:, 6].sum() / max(tm[:, 5].sum(), 1), tm[:, 7].sum() / max(tm[:, 5].sum(), 1), 100 * tm[:, 7].sum() / tot))
-    ts = np.zeros((8192, 8), dtype=np.uint64)
-    L.rt_debug_setup_timing.argtypes = [C.c_void_p, C.c_size_t]
-    L.rt_debug_setup_timing(ts.ctypes.data, ts.size)
-    ts = ts[ts[:, 0] > 0].astype(np.float64)
-    print('   setup: waves %d cycles mean %.0f max %.0f prefix %.0f chunks mean %.1f | per chunk: load %.0f analytic %.0f instances %.0f tail %.0f' % (
-        len(ts), ts[:, 0].mean(), ts[:, 0].max(), ts[:, 1].mean(), ts[:, 2].mean(), ts[:, 3].sum() / ts[:, 2].sum(), ts[:, 4].sum() / ts[:, 2].sum(), ts[:, 5].sum() / ts[:, 2].sum(), ts[:, 6].sum() / ts[:, 2].sum()))
