@@ -210,7 +210,8 @@ __device__ __forceinline__ bool slab(float lx, float ly, float lz, float hx, flo
 #define RT_LEAF_BATCH 32
 #endif
 #ifndef RT_REFILL_IDLE
-#define RT_REFILL_IDLE 16          // idle lanes of a wave that make it fetch new pairs
+#define RT_REFILL_IDLE 32          // idle lanes of a wave that make it fetch new pairs (with 4-wide nodes: 16: 1.243, 24: 1.234,
+                                   // 32: 1.222, 40: 1.28 ms of BVH walk per 1080p bunnies frame)
 #endif
 #ifndef RT_SHARE_IDLE
 #define RT_SHARE_IDLE 16           // idle lanes that make a wave without input share its pending subtrees
