@@ -124,7 +124,7 @@ def main():
                     help="independent passes a rank keeps queued (own scene handle, stream and buffers each); 1 = one after the other")
     ap.add_argument("--views-per-pass", type=int, default=0,
                     help="frames that travel through the recursion depths together (rt_scene_set_views); 0 = chosen from --steps and --gpus")
-    ap.add_argument("--same-camera", action="store_true", help="every frame in flight uses the scene's own camera (the round-1 schedule)")
+    ap.add_argument("--same-camera", action="store_true", help="every frame in flight uses the scene's own camera (as an earlier version of this benchmark did)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="all ranks share cuda:0 and gather over gloo: checks the N>1 code path on a one-GPU box, not a measurement")
     ap.add_argument("--watchdog", type=int, default=900, help="seconds after which a stuck run prints its stacks and exits non-zero (0 = off)")

@@ -19,8 +19,10 @@
 //                         matrices), in the reference's exact evaluation order; only launched for scenes that need it
 //      B   rt_traverse    BVH walk, one walk item per lane, lanes refilled as they finish - every lane
 //                         that is busy is busy with the same code
-//      C   rt_shade       closest hit -> hit point, material, child rays and shadow rays; then the Phong sums
-//                         of the previous depth's hits, whose shadow rays were traced at this depth
+//      C   rt_shade       closest hit -> hit point, material, child rays and hit records; then the Phong sums
+//                         of the previous depth's hits, whose shadow rays were traced at this depth; then, for
+//                         scenes with few instances, step A of the next depth for the rays the block has just
+//                         made (rt_setup itself then only runs at depth 0)
 //    Splitting by kind of work is what keeps the 64 lanes of a wave busy: in a one-kernel version
 //    fewer than 5 % of the lanes had a BVH node to visit in a given round.
 //  * Lists are appended to without device-wide atomics (about 10 ns each when contended, all
@@ -1573,7 +1575,7 @@ __device__ void phong_pass(const DScene& S, const DFrame& F, const uint32_t leve
 
 // ======================================================================================================
 // Kernel C: per ray of this depth, what raytrace_impl / shade do once the closest hit is known
-// (raytracer.rs:65-135), except the Phong sum, which has to wait for its shadow rays (kernel D).
+// (raytracer.rs:65-135), except the Phong sum, which has to wait for its shadow rays (phong_pass, one depth later).
 // Shadow rays only record their verdict (raytracer.rs:171-187).
 // ======================================================================================================
 // five waves per SIMD: the kernel needs 97 registers, which the allocation granule would round up to four waves'
@@ -1696,7 +1698,7 @@ __global__ void __launch_bounds__(RT_SHADE_THREADS) rt_shade(const DScene S, con
                     }
                 } else {
                     if (S.n_lights > 0) {
-                        emit_hit = true;                                   // shade_phong, finished by kernel D
+                        emit_hit = true;                                   // shade_phong, finished by phong_pass
                     } else if (mtype == RT_MATERIAL_PHONG) {
                         add_color(F, pixel, background(S, cur.ray.d) * cur.throughput);      // shade() returned None: as a miss
                     }
