@@ -52,12 +52,56 @@ int main(int argc, char** argv) {
         RtRenderParams p;
         memset(&p, 0, sizeof(p));
         p.max_depth = (uint32_t)depth; p.output_format = RT_FORMAT_RGB8; p.shard_index = 0; p.shard_count = 1;
-        const int rc = rt_render(scene, &p, rgb.data(), &aux);
-        if (rc != RT_OK) { fprintf(stderr, "%s: render: %s\n", path, rt_last_error()); ++failures; }
+        // EMU_MODE picks another entry point for the same picture (colours only, no aux planes):
+        //   shards:<n>  n tile shards through rt_render_device, then rt_assemble_shards
+        //   views:<n>   n views of the same camera in one pass (rt_scene_set_views); the first is written, all must be equal
+        //   noalloc     rt_render_device_noalloc
+        //   depthmap    rt_render in depth-map mode
+        const char* mode = getenv("EMU_MODE");
+        int rc = RT_OK;
+        bool with_aux = false;
+        if (mode && !strncmp(mode, "shards:", 7)) {
+            const uint32_t shards = (uint32_t)atoi(mode + 7);
+            p.shard_count = shards;
+            uint64_t bytes = 0;
+            rc = rt_shard_bytes(scene, &p, &bytes);
+            std::vector<uint8_t> gathered((size_t)bytes * shards);
+            for (uint32_t k = 0; k < shards && rc == RT_OK; ++k) {
+                p.shard_index = k;
+                rc = rt_render_device(scene, &p, gathered.data() + (size_t)bytes * k);
+                uint64_t counters[RT_N_COUNTERS];
+                if (rc == RT_OK) rc = rt_last_ray_counts(scene, counters);
+            }
+            if (rc == RT_OK) rc = rt_assemble_shards(scene, &p, gathered.data(), rgb.data());
+        } else if (mode && !strncmp(mode, "views:", 6)) {
+            const uint32_t views = (uint32_t)atoi(mode + 6);
+            std::vector<float> ms((size_t)16 * views);
+            for (uint32_t v = 0; v < views; ++v) memcpy(&ms[16 * v], m, sizeof(m));
+            rc = rt_scene_set_views(scene, ms.data(), views, w, h);
+            std::vector<uint8_t> all(n * 3 * views);
+            if (rc == RT_OK) rc = rt_render(scene, &p, all.data(), nullptr);
+            for (uint32_t v = 1; v < views && rc == RT_OK; ++v)
+                if (memcmp(all.data(), all.data() + n * 3 * v, n * 3)) { fprintf(stderr, "%s: view %u differs from view 0\n", path, v); rc = -100; }
+            memcpy(rgb.data(), all.data(), n * 3);
+        } else if (mode && !strcmp(mode, "noalloc")) {
+            rc = rt_render_device_noalloc(scene, &p, rgb.data());
+            uint64_t counters[RT_N_COUNTERS];
+            if (rc == RT_OK) rc = rt_last_ray_counts(scene, counters);
+        } else if (mode && !strcmp(mode, "depthmap")) {
+            p.mode = RT_MODE_DEPTH_MAP;
+            rc = rt_render(scene, &p, rgb.data(), nullptr);
+        } else {
+            with_aux = true;
+            rc = rt_render(scene, &p, rgb.data(), &aux);
+        }
+        if (rc != RT_OK) { fprintf(stderr, "%s: render: %s\n", path, rc == -100 ? "views differ" : rt_last_error()); ++failures; }
         else {
-            dump(out + ".rgb", rgb.data(), rgb.size()); dump(out + ".prim", prim.data(), n * 4); dump(out + ".inst", inst.data(), n * 4);
-            dump(out + ".flags", flags.data(), n); dump(out + ".t", t.data(), n * 4); dump(out + ".counters", aux.counters, sizeof(aux.counters));
-            printf("%s: %ux%u depth %d rays %llu\n", path, w, h, depth, (unsigned long long)aux.counters[0]);
+            dump(out + ".rgb", rgb.data(), rgb.size());
+            if (with_aux) {
+                dump(out + ".prim", prim.data(), n * 4); dump(out + ".inst", inst.data(), n * 4);
+                dump(out + ".flags", flags.data(), n); dump(out + ".t", t.data(), n * 4); dump(out + ".counters", aux.counters, sizeof(aux.counters));
+            }
+            printf("%s: %ux%u depth %d mode %s rays %llu\n", path, w, h, depth, mode ? mode : "plain", (unsigned long long)aux.counters[0]);
             fflush(stdout);
         }
         rt_scene_destroy(scene);
