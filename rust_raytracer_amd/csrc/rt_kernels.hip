@@ -33,6 +33,8 @@
 // without fast-math so that no FMA is formed and division / sqrt stay correctly rounded.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "rt_device.h"
 #ifdef RT_STATS
 #include <cstdlib>
@@ -1580,15 +1582,19 @@ __device__ void phong_pass(const DScene& S, const DFrame& F, const uint32_t leve
 // ======================================================================================================
 // five waves per SIMD: the kernel needs 97 registers, which the allocation granule would round up to four waves'
 // worth; the list kernels run five blocks per compute unit
-__attribute__((amdgpu_waves_per_eu(5, 5)))
+#ifndef RT_SHADE_WAVES
+#define RT_SHADE_WAVES 5
+#endif
+__attribute__((amdgpu_waves_per_eu(RT_SHADE_WAVES, RT_SHADE_WAVES)))
 __global__ void __launch_bounds__(RT_SHADE_THREADS) rt_shade(const DScene S, const DFrame F, const uint32_t level, const uint32_t setup_next) {
     const LevelLists L = level_lists(F, level);
     extern __shared__ uint32_t lds[];
-    uint32_t* pre = lds;
-    uint32_t* scratch = lds + F.n_seg + 1;
-    // only with setup_next: the slots this block takes from the shared overflow segments, then what setup_rays needs
-    uint32_t* extra_rays = lds + F.n_seg + 1 + RT_MAX_LIST_THREADS;
+    // With setup_next the block first keeps the slots it takes from the shared overflow segments; what setup_rays needs
+    // later (staged primitives, range-tree stacks, rings) lies over the prefix table, which is done with by then.
+    uint32_t* extra_rays = lds;
     uint32_t* extra_hits = extra_rays + RT_LOCAL_EXTRA_RAYS;
+    uint32_t* pre = setup_next ? extra_hits + RT_LOCAL_EXTRA_HITS : lds;
+    uint32_t* scratch = pre + F.n_seg + 1;
     __shared__ uint32_t out_rays, out_hits, n_extra_rays, n_extra_hits, fat_n, slow_n;
     if (threadIdx.x == 0) { out_rays = 0; out_hits = 0; n_extra_rays = 0; n_extra_hits = 0; fat_n = 0; slow_n = 0; }
     const uint32_t p = level & 1, q = p ^ 1;
@@ -1769,7 +1775,7 @@ __global__ void __launch_bounds__(RT_SHADE_THREADS) rt_shade(const DScene S, con
         in.extra_rays = extra_rays; in.extra_hits = extra_hits;
         in.n_rays = in.own_rays + (n_extra_rays < RT_LOCAL_EXTRA_RAYS ? n_extra_rays : RT_LOCAL_EXTRA_RAYS);
         in.n_hits = in.own_hits + (n_extra_hits < RT_LOCAL_EXTRA_HITS ? n_extra_hits : RT_LOCAL_EXTRA_HITS);
-        uint32_t* stage = extra_hits + RT_LOCAL_EXTRA_HITS;
+        uint32_t* stage = pre;                                        // every wave has left phong_pass (barrier above)
         stage_analytic(S, stage);
         setup_rays<true>(S, F, level + 1, in, stage, &fat_n, &slow_n);
     }
@@ -1902,8 +1908,8 @@ extern "C" hipError_t rt_launch_level(const DScene* S, const DFrame* F, uint32_t
 #endif
     if (marks) (void)hipEventRecord(marks[2], stream);
     const uint32_t setup_next = (F->fuse_setup && level < last) ? 1u : 0u;
-    hipLaunchKernelGGL(rt_shade, dim3(blocks), dim3(RT_SHADE_THREADS),
-                       lds + (setup_next ? (RT_LOCAL_EXTRA_RAYS + RT_LOCAL_EXTRA_HITS + setup_words) * sizeof(uint32_t) : 0), stream, *S, *F, level, setup_next);
+    const size_t shade_lds = setup_next ? (RT_LOCAL_EXTRA_RAYS + RT_LOCAL_EXTRA_HITS) * sizeof(uint32_t) + std::max(lds, setup_words * sizeof(uint32_t)) : lds;
+    hipLaunchKernelGGL(rt_shade, dim3(blocks), dim3(RT_SHADE_THREADS), shade_lds, stream, *S, *F, level, setup_next);
     if (marks) (void)hipEventRecord(marks[3], stream);
     return hipGetLastError();
 }
