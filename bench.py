@@ -358,7 +358,10 @@ def main():
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
     elapsed, elapsed_sequential = (float(x) for x in t.cpu())
     rays = rays.cpu().numpy()
-    region_rays, frame_rays, walk_nodes, walk_tris = rays[:5], rays[5:10], int(rays[10]), int(rays[11])
+    region_rays, frame_rays = rays[:5], rays[5:10]
+    # the roofline is that of THIS rank's launches: its own shard's rays and walk work, not the frame's
+    shard_rays = [int(x) for x in own_counts[:5]]
+    walk_nodes, walk_tris = int(own_counts[abi.RT_CTR_WALK_NODE_VISITS]), int(own_counts[abi.RT_CTR_WALK_TRIANGLE_TESTS])
 
     if rank == 0:
         rays_per_frame = int(frame_rays[0])
@@ -402,9 +405,10 @@ def main():
         avg_launch_ms = ms_sum / launches if launches else None
         traffic_file = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
         traffic = None
-        if os.path.exists(traffic_file):
+        if os.path.exists(traffic_file) and world == 1:                 # the counters were collected on whole frames of one GPU
             traffic = json.load(open(traffic_file)).get("kernels", {}).get(dominant, {}).get("hbm_bytes_per_launch")
         roofline = {"kernel": dominant, "launches_per_frame": per_frame_launches, "avg_launch_ms": avg_launch_ms,
+                    "scope": "the whole frame" if world == 1 else "rank 0's launches: its 1/%d shard of the frame (work counted on that shard)" % world,
                     "kernels_ms_per_frame": per_frame_ms, "trace_ms_per_frame": trace_ms, "frame_kernel_ms": frame_ms,
                     "traffic": traffic}
         if launches:
@@ -421,7 +425,7 @@ def main():
                 roofline.update({"bound": "valu", "achieved": achieved, "peak": FP32_NO_FMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                  "frac": achieved / FP32_NO_FMA_PEAK_TFLOPS,
                                  "work": {"node_visits_per_frame": walk_nodes, "triangle_tests_per_frame": walk_tris,
-                                          "flops_per_frame": flops, "flops_per_ray": flops / max(rays_per_frame, 1),
+                                          "flops_per_frame": flops, "flops_per_ray": flops / max(shard_rays[0], 1),
                                           "counted_by": "the kernel itself (RT_CTR_WALK_*), %d flop per box test x %d boxes per node visit, "
                                                         "%d per triangle test" % (FLOPS_PER_BOX_TEST, BOXES_PER_NODE_VISIT, FLOPS_PER_TRIANGLE_TEST)},
                                  "hbm": hbm})
@@ -433,10 +437,10 @@ def main():
                         "what": "bytes and flops of the reference's UN-PRUNED walk (oracle-counted) / this kernel's time: an equivalent "
                                 "rate, not work done and no roofline fraction"}
             else:
-                nbytes = list_kernel_bytes(frame_rays, n_lights, kernel_ms["rt_setup"][1], kernel_ms["rt_shade"][1])[dominant]
+                nbytes = list_kernel_bytes(shard_rays, n_lights, kernel_ms["rt_setup"][1], kernel_ms["rt_shade"][1])[dominant]
                 achieved = nbytes / per_frame_launches / seconds / 1e9
                 roofline.update({"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                                 "work": {"bytes_per_frame": nbytes, "bytes_per_ray": nbytes / max(rays_per_frame, 1),
+                                 "work": {"bytes_per_frame": nbytes, "bytes_per_ray": nbytes / max(shard_rays[0], 1),
                                           "counted_by": "record sizes x the frame's ray counts (list_kernel_bytes in bench.py)"},
                                  "measured_hbm": hbm})
         out["roofline"] = roofline
