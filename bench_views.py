@@ -38,7 +38,7 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    from rust_raytracer_amd import meshes, native, synthetic
+    from rust_raytracer_amd import abi, meshes, native, synthetic
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -87,7 +87,16 @@ def main():
                 total += devs[s].last_ray_counts()[:5].astype(np.int64)  # waits; also raises if a ray list overflowed
         return total
 
-    rays = batch(count_rays=True)            # warm-up that also counts the batch's rays (deterministic per view)
+    # Warm-up that also counts the batch's rays (deterministic per view).  A handle's first frames may be reported incomplete
+    # - ray lists that have to grow, or stray rays (NaN components) that switch the exact-path kernel on for the handle -:
+    # rt_render_device cannot redo a frame itself, so the batch is simply rendered again until every pass is whole.
+    for attempt in range(8):
+        try:
+            rays = batch(count_rays=True)
+            break
+        except native.RtError as e:
+            if e.code != abi.RT_ERR_OUT_OF_RANGE or attempt == 7:
+                raise
     for _ in range(max(args.warmup, 1)):
         batch()
         torch.cuda.synchronize()
