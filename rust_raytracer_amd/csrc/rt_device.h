@@ -20,7 +20,7 @@
 struct float4 { float x, y, z, w; };
 #endif
 
-#define RT_STACK_LDS_MAX 16         // traversal stack entries per lane kept in LDS
+#define RT_STACK_LDS_MAX 12         // traversal stack entries per lane kept in LDS (four blocks of the BVH walk per compute unit)
 #define RT_MAX_DEPTH_LIMIT 63      // depth is carried in 6 bits of a ray record
 #define RT_MAX_PIXELS_PER_SHARD (1u << 25)
 #define RT_META_RAY_LIMIT 0x7FFFFFFFull   // ray slots are 31-bit numbers

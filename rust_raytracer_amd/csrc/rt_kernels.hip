@@ -1201,12 +1201,12 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
     bool pending = false;           // walk finished, its part in the pair's result not yet settled
     uint32_t item = 0, gi = 0, ii = 0, sp = 0, base = 0, owner = lane;
     uint32_t pending_leaf = RT_REF_NONE;                            // a leaf this lane has reached and not yet tested
-    // The entry the lane looks at next is already off the stack: its reference, its box entry distance and, for
-    // an inner node, the node itself, requested at the end of the previous step so that the fetch overlaps
-    // whatever the wave does in between.
+    // The entry the lane looks at next is already off the stack: its reference and its box entry distance.  The node
+    // itself is fetched when it is visited: requesting it a step ahead kept 28 more registers alive through the leaf tests
+    // and the service phase, and the kernel at three waves per SIMD; with the leaves tested in two groups as well it needs
+    // 112 registers and runs four (BVH walk of the 1080p bunnies frame 1.22 -> 1.16 ms, of the 2.6 M-triangle grid 6.25 -> 5.73).
     uint32_t cur_ref = RT_REF_NONE;
     float cur_t = 0.0f;
-    float4 nd0 = make_float4(0, 0, 0, 0), nd1 = nd0, nd2 = nd0, nd3 = nd0, nd4 = nd0, nd5 = nd0, nd6 = nd0;
     Ray lr; lr.o = lr.d = mk(0, 0, 0);
     V3 inv = mk(0, 0, 0);
     bool fast = false;
@@ -1315,10 +1315,6 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
                     m_have = false; m_t = 0.0f; m_u = 0.0f; m_v = 0.0f; m_slot = 0;
                     cur_ref = __float_as_uint(q2.w);
                     cur_t = q0.w;
-                    if (!(cur_ref & RT_REF_LEAF_BIT)) {
-                        const float4* nq = S.nodes4 + 8 * (size_t)cur_ref;
-                        nd0 = nq[0]; nd1 = nq[1]; nd2 = nq[2]; nd3 = nq[3]; nd4 = nq[4]; nd5 = nq[5]; nd6 = nq[6];
-                    }
                     sp = 0; base = 0;
                     owner = lane;
                     recs[4 * lane] = 0xFFFFFFFFu; recs[4 * lane + 1] = 0xFFFFFFFFu;
@@ -1359,10 +1355,6 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
                     m_have = false; m_t = 0.0f; m_u = 0.0f; m_v = 0.0f; m_slot = 0;
                     cur_ref = wave_stack[s_base * RT_WAVE + src];           // an inner node: leaves are not given away
                     cur_t = __uint_as_float(wave_stack[(stack_lds + s_base) * RT_WAVE + src]);
-                    {
-                        const float4* nq = S.nodes4 + 8 * (size_t)cur_ref;
-                        nd0 = nq[0]; nd1 = nq[1]; nd2 = nq[2]; nd3 = nq[3]; nd4 = nq[4]; nd5 = nq[5]; nd6 = nq[6];
-                    }
                     sp = 0; base = 0;
                     running = true;
                 }
@@ -1391,22 +1383,30 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
                     bool improved = false;
                     // all of the leaf's triangles are fetched before the first test, so that the fetches overlap
                     // (entries past the leaf's count repeat its last triangle and are not tested)
-                    float4 h[RT_LEAF_TRIANGLES][3];
+                    // the leaf's triangles in two groups (three, then two): each group is fetched before its first test, so
+                    // that the fetches overlap, without holding all five triangles in registers at once
 #pragma unroll
-                    for (uint32_t k = 0; k < RT_LEAF_TRIANGLES; ++k) {
-                        const uint32_t slot = first + (k < cnt ? k : cnt - 1);
-                        h[k][0] = S.tri_hot[3 * slot]; h[k][1] = S.tri_hot[3 * slot + 1]; h[k][2] = S.tri_hot[3 * slot + 2];
-                    }
+                    for (uint32_t g0 = 0; g0 < RT_LEAF_TRIANGLES; g0 += 3) {
+                        if (g0 >= cnt) break;
+                        float4 h[3][3];
 #pragma unroll
-                    for (uint32_t k = 0; k < RT_LEAF_TRIANGLES; ++k) {
-                        const uint32_t slot = first + k;
-                        float t, u, v;
-                        if (k < cnt &&
-                            triangle_tuv(mk(h[k][0].x, h[k][0].y, h[k][0].z), mk(h[k][0].w, h[k][1].x, h[k][1].y),
-                                         mk(h[k][1].z, h[k][1].w, h[k][2].x), lr, t, u, v) &&
-                            (!m_have || t < m_t || (t == m_t && slot < m_slot))) {
-                            m_have = true; m_t = t; m_u = u; m_v = v; m_slot = slot;
-                            improved = true;
+                        for (uint32_t k = 0; k < 3; ++k) {
+                            if (g0 + k >= RT_LEAF_TRIANGLES) break;
+                            const uint32_t slot = first + (g0 + k < cnt ? g0 + k : cnt - 1);
+                            h[k][0] = S.tri_hot[3 * slot]; h[k][1] = S.tri_hot[3 * slot + 1]; h[k][2] = S.tri_hot[3 * slot + 2];
+                        }
+#pragma unroll
+                        for (uint32_t k = 0; k < 3; ++k) {
+                            if (g0 + k >= RT_LEAF_TRIANGLES) break;
+                            const uint32_t slot = first + g0 + k;
+                            float t, u, v;
+                            if (g0 + k < cnt &&
+                                triangle_tuv(mk(h[k][0].x, h[k][0].y, h[k][0].z), mk(h[k][0].w, h[k][1].x, h[k][1].y),
+                                             mk(h[k][1].z, h[k][1].w, h[k][2].x), lr, t, u, v) &&
+                                (!m_have || t < m_t || (t == m_t && slot < m_slot))) {
+                                m_have = true; m_t = t; m_u = u; m_v = v; m_slot = slot;
+                                improved = true;
+                            }
                         }
                     }
                     if (improved) {
@@ -1447,6 +1447,8 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
                 } else {
                     // up to four entries, stored in the order the reference's walk would reach them
                     ++n_node_visits;
+                    const float4* nq = S.nodes4 + 8 * (size_t)cur_ref;
+                    const float4 nd0 = nq[0], nd1 = nq[1], nd2 = nq[2], nd3 = nq[3], nd4 = nq[4], nd5 = nq[5], nd6 = nq[6];
                     float t0, t1, t2, t3;
                     const bool h0 = slab(nd0.x, nd0.y, nd0.z, nd0.w, nd1.x, nd1.y, lr.o, inv, t0);
                     const bool h1 = slab(nd1.z, nd1.w, nd2.x, nd2.y, nd2.z, nd2.w, lr.o, inv, t1);
@@ -1488,10 +1490,6 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
                 }
             }
             cur_ref = next_ref; cur_t = next_t;
-            if (cur_ref != RT_REF_NONE && !(cur_ref & RT_REF_LEAF_BIT)) {
-                const float4* nq = S.nodes4 + 8 * (size_t)cur_ref;
-                nd0 = nq[0]; nd1 = nq[1]; nd2 = nq[2]; nd3 = nq[3]; nd4 = nq[4]; nd5 = nq[5]; nd6 = nq[6];
-            }
         }
         if (running && pending_leaf == RT_REF_NONE && cur_ref == RT_REF_NONE && sp == base) {
             running = false;                                         // settled in the next service phase

@@ -11,6 +11,7 @@
 #include "../../include/rt_hip.h"
 #include "../../include/rt_host.h"
 extern "C" int rt_debug_set_queue_capacity(RtScene* s, uint32_t capacity);
+extern "C" int rt_debug_last_regrown(RtScene* s, uint32_t* out);
 
 static void dump(const std::string& path, const void* p, size_t n) {
     FILE* f = fopen(path.c_str(), "wb");
@@ -101,7 +102,9 @@ int main(int argc, char** argv) {
                 dump(out + ".prim", prim.data(), n * 4); dump(out + ".inst", inst.data(), n * 4);
                 dump(out + ".flags", flags.data(), n); dump(out + ".t", t.data(), n * 4); dump(out + ".counters", aux.counters, sizeof(aux.counters));
             }
-            printf("%s: %ux%u depth %d mode %s rays %llu\n", path, w, h, depth, mode ? mode : "plain", (unsigned long long)aux.counters[0]);
+            uint32_t redone = 0;
+            rt_debug_last_regrown(scene, &redone);
+            printf("%s: %ux%u depth %d mode %s rays %llu, rendered %u time(s)\n", path, w, h, depth, mode ? mode : "plain", (unsigned long long)aux.counters[0], redone + 1);
             fflush(stdout);
         }
         rt_scene_destroy(scene);
