@@ -486,7 +486,7 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device_id, RtScene**
                         for (int c = 0; c < 3; ++c) { lo[c] = empty ? INFINITY : di.world_lo[c]; hi[c] = empty ? -INFINITY : di.world_hi[c]; }
                         *limit = empty ? INFINITY : di.cull_origin_limit;
                         nodes[2 * k] = f4(lo[0], lo[1], lo[2], bits(empty ? 0xFFFFFFFFu : (0x80000000u | a)));
-                        nodes[2 * k + 1] = f4(hi[0], hi[1], hi[2], bits(0u));
+                        nodes[2 * k + 1] = f4(hi[0], hi[1], hi[2], bits(k + 1));
                         limits[k] = *limit;
                         return k;
                     }
@@ -495,15 +495,16 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device_id, RtScene**
                     const uint32_t left = run(a, mid, level + 1, llo, lhi, &ll), right = run(mid, b, level + 1, rlo, rhi, &rl);
                     for (int c = 0; c < 3; ++c) { lo[c] = std::min(llo[c], rlo[c]); hi[c] = std::max(lhi[c], rhi[c]); }
                     *limit = std::min(ll, rl);
-                    nodes[2 * k] = f4(lo[0], lo[1], lo[2], bits(left));
-                    nodes[2 * k + 1] = f4(hi[0], hi[1], hi[2], bits(right));
+                    (void)left; (void)right;                                     // pre-order: the left child is node k + 1, the right one follows its subtree
+                    nodes[2 * k] = f4(lo[0], lo[1], lo[2], bits(0u));
+                    nodes[2 * k + 1] = f4(hi[0], hi[1], hi[2], bits((uint32_t)limits.size()));
                     limits[k] = *limit;
                     return k;
                 }
             } build{instances, range_nodes, range_limits};
             float lo[3], hi[3], limit;
             build.run(0, (uint32_t)instances.size(), 1, lo, hi, &limit);
-            range_depth = build.depth + 1;
+            range_depth = 0;                                          // (the walk keeps no stack, see rt_setup)
         }
     }
     s->d.n_range_nodes = (uint32_t)range_limits.size();

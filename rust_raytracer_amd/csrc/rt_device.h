@@ -92,13 +92,15 @@ struct DScene {
     uint32_t stack_lds;          // how many of them live in LDS (the rest, rarely reached, in DFrame::spill)
     uint32_t all_cullable;       // every instance has a usable culling box (DInstance::cullable)
     // Scenes with many instances: a binary tree over index ranges of the instances (node 0 = all of them, children
-    // split a range in the middle), each node with the union of its instances' culling boxes.  Visiting the left
-    // child first meets the instances in Vec order, which is the order the pairs of a ray must be emitted in.
-    //   inner node k: range_nodes[2k] = (box min, bits left child node), [2k+1] = (box max, bits right child node)
-    //   leaf k (one instance): range_nodes[2k].w = bits (0x80000000 | instance), or 0xFFFFFFFF for an empty mesh
+    // split a range in the middle), each node with the union of its instances' culling boxes, stored in pre-order: the
+    // left child of node k is node k + 1, and everything up to `end` belongs to k's subtree.  Walking the array forwards
+    // and jumping to `end` where a box is missed meets the instances in Vec order, which is the order the pairs of a ray
+    // must be emitted in.
+    //   node k: range_nodes[2k] = (box min, bits leaf word), [2k+1] = (box max, bits end)
+    //   leaf word: 0 for an inner node, 0x80000000 | instance for a leaf, 0xFFFFFFFF for the leaf of an empty mesh
     //   range_limits[k] = smallest cull_origin_limit in the range
     uint32_t n_range_nodes;      // 0: rt_setup scans the instances linearly
-    uint32_t range_depth;        // stack entries a walk of the tree can need
+    uint32_t range_depth;        // (unused: the walk of the tree keeps no stack)
     const float4* range_nodes;
     const float* range_limits;
     const DLight* lights;

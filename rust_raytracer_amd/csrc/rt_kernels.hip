@@ -931,31 +931,32 @@ __device__ __forceinline__ void setup_rays(const DScene& S, const DFrame& F, con
         if (have && best_t < lw) lw = best_t;
         const float lw_cut = lw * 1.000244140625f;
         if (S.n_range_nodes) {
-            // Many instances: each lane walks the range tree, left child first, so it meets its instances in Vec order; the
-            // wave steps through the walks together so that it can empty the ring in between
-            uint32_t* walk = stage + stage_words + threadIdx.x;          // entry e of this lane: walk[e * blockDim.x]
-            uint32_t sp = 0;
-            if (active && !settled) { walk[0] = 0u; sp = 1; }
-            while (__ballot(sp != 0)) {
-                bool want_item = false;
-                uint32_t ii = 0;
-                if (sp) {
-                    const uint32_t k = walk[--sp * blockDim.x];
-                    const float4 n0 = S.range_nodes[2 * k], n1 = S.range_nodes[2 * k + 1];
-                    float tmin_w;
-                    const bool pass = !(o_l1 < S.range_limits[k]) ||
-                                      (slab(n0.x, n0.y, n0.z, n1.x, n1.y, n1.z, r.o, inv_w, tmin_w) && !(tmin_w > lw_cut));
-                    const uint32_t left = __float_as_uint(n0.w);
-                    if (pass && (left & 0x80000000u)) {
-                        if (left != 0xFFFFFFFFu) { want_item = true; ii = left & 0x7FFFFFFFu; }
-                    } else if (pass) {
-                        walk[sp++ * blockDim.x] = __float_as_uint(n1.w);
-                        walk[sp++ * blockDim.x] = left;
+            // Many instances: the wave walks the range tree together.  The tree is stored in pre-order, so a ray's walk is a
+            // forward scan that jumps over the subtrees whose box it misses; k is the first node any lane still has to look at
+            // (lanes that are past it wait), and since every lane that is not at k has jumped over a subtree that contains k,
+            // the next such node is k + 1 if a lane at k goes down into it and the end of k's subtree otherwise.  k is
+            // wave-uniform: the nodes come through scalar loads, no lane keeps a stack, and every lane meets its instances in
+            // Vec order.  (Fetching the two nodes the scan can go to next ahead of time made it slower.)
+            uint32_t at = (active && !settled) ? 0u : S.n_range_nodes;     // the node this lane looks at next
+            uint32_t k = __ballot(at == 0u) ? 0u : S.n_range_nodes;
+            while (k < S.n_range_nodes) {
+                const float4 n0 = S.range_nodes[2 * k], n1 = S.range_nodes[2 * k + 1];
+                const uint32_t leaf_word = __float_as_uint(n0.w), end = __float_as_uint(n1.w);
+                const bool here = at == k;
+                float tmin_w;
+                const bool pass = here && (!(o_l1 < S.range_limits[k]) ||
+                                           (slab(n0.x, n0.y, n0.z, n1.x, n1.y, n1.z, r.o, inv_w, tmin_w) && !(tmin_w > lw_cut)));
+                if (leaf_word & 0x80000000u) {
+                    const bool want_item = pass && leaf_word != 0xFFFFFFFFu;
+                    if (__ballot(want_item)) {
+                        ring_push(R, want_item, r, lw, gi, leaf_word & 0x7FFFFFFFu, rr, ss, lane);
+                        if (R.count >= RT_WAVE) ring_drain(R, S, F, L, &out_n, lane);
                     }
-                }
-                if (__ballot(want_item)) {
-                    ring_push(R, want_item, r, lw, gi, ii, rr, ss, lane);
-                    if (R.count >= RT_WAVE) ring_drain(R, S, F, L, &out_n, lane);
+                    if (here) at = end;                                      // = k + 1
+                    k = end;
+                } else {
+                    if (here) at = pass ? k + 1u : end;
+                    k = __ballot(pass) ? k + 1u : end;
                 }
             }
         }
