@@ -801,6 +801,14 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_generate(const DFrame F, 
 // Diagnostic build: per wave of the last rt_traverse launch: cycles, rounds, refill cycles, refills, cycles and
 // count of rounds in which some lane tested a leaf, cycles and count of the other rounds, sum of walking lanes.
 __device__ unsigned long long g_wave_timing[8192 * 10];
+__device__ unsigned long long g_shade_timing[8192 * 8];
+extern "C" hipError_t rt_debug_shade_timing(unsigned long long* out, size_t n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_shade_timing), n * sizeof(unsigned long long));
+}
+__device__ unsigned int g_walk_items[64];
+extern "C" hipError_t rt_debug_walk_items(unsigned int* out, size_t n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_walk_items), n * sizeof(unsigned int));
+}
 extern "C" hipError_t rt_debug_wave_timing(unsigned long long* out, size_t n) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_timing), n * sizeof(unsigned long long));
 }
@@ -1165,6 +1173,9 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_setup_slow(const DScene S
 // ======================================================================================================
 
 __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, const DFrame F, const uint32_t level) {
+#ifdef RT_STATS
+    const unsigned long long t_begin = clock64(), w_begin = wall_clock64();
+#endif
     const LevelLists L = level_lists(F, level);
     extern __shared__ uint32_t lds[];
     uint32_t* pre = lds;
@@ -1217,7 +1228,9 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
 #ifdef RT_STATS
     uint32_t dbg_steps = 0;
     unsigned long long tm[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const unsigned long long t_begin = clock64();
+    tm[2] = clock64() - t_begin;           // building the prefix table
+    if (threadIdx.x == 0 && blockIdx.x == 0 && level < 64) g_walk_items[level] = n_items;
+    tm[3] = w_begin;                       // start and end of the wave on the constant 100 MHz clock
 #endif
 
     auto stack_push = [&](uint32_t e, uint32_t ref, float t) {
@@ -1505,6 +1518,7 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
     }
 #ifdef RT_STATS
     tm[0] = clock64() - t_begin;
+    tm[4] = wall_clock64();
     if (lane == 0 && gwave < 8192) for (int k = 0; k < 10; ++k) g_wave_timing[gwave * 10 + k] = tm[k];
 #endif
 }
@@ -1586,6 +1600,10 @@ __device__ void phong_pass(const DScene& S, const DFrame& F, const uint32_t leve
 #endif
 __attribute__((amdgpu_waves_per_eu(RT_SHADE_WAVES, RT_SHADE_WAVES)))
 __global__ void __launch_bounds__(RT_SHADE_THREADS) rt_shade(const DScene S, const DFrame F, const uint32_t level, const uint32_t setup_next) {
+#ifdef RT_STATS
+    unsigned long long ts[8];
+    ts[0] = clock64();
+#endif
     const LevelLists L = level_lists(F, level);
     extern __shared__ uint32_t lds[];
     // With setup_next the block first keeps the slots it takes from the shared overflow segments; what setup_rays needs
@@ -1605,6 +1623,9 @@ __global__ void __launch_bounds__(RT_SHADE_THREADS) rt_shade(const DScene S, con
     const uint32_t gwave = (blockIdx.x * blockDim.x + threadIdx.x) / RT_WAVE;
     const uint32_t n_waves = gridDim.x * (blockDim.x / RT_WAVE);
     uint32_t n_primary = 0, n_shadow = 0, n_reflected = 0, n_transmitted = 0;
+#ifdef RT_STATS
+    ts[1] = clock64();
+#endif
 
     for (uint32_t c = gwave; (unsigned long long)c * RT_WAVE < n_rays; c += n_waves) {
         const uint32_t v = c * RT_WAVE + lane;
@@ -1743,6 +1764,9 @@ __global__ void __launch_bounds__(RT_SHADE_THREADS) rt_shade(const DScene S, con
         }
     }
 
+#ifdef RT_STATS
+    ts[2] = clock64();
+#endif
     // ---- ray statistics: every wave owns a row of F.wave_stats (no atomics) ----------------------------
     {
         uint32_t vals[5] = {n_primary + n_shadow + n_reflected + n_transmitted, n_primary, n_shadow, n_reflected, n_transmitted};
@@ -1758,7 +1782,13 @@ __global__ void __launch_bounds__(RT_SHADE_THREADS) rt_shade(const DScene S, con
         L.next_hit_counts[blockIdx.x] = out_hits < F.seg_hits ? out_hits : F.seg_hits;
     }
     // the hits of the depth above are complete now that this depth's rays - their shadow rays among them - are traced
+#ifdef RT_STATS
+    ts[3] = clock64();
+#endif
     if (level > 0 && S.n_lights > 0) phong_pass(S, F, level, pre, scratch);
+#ifdef RT_STATS
+    ts[4] = clock64();
+#endif
     // ---- the next depth's rt_setup, block by block: the rays and hit records this block has just appended are all it needs,
     // and a block is the only writer of its segments, so no other block has to be waited for
     if (setup_next) {
@@ -1778,6 +1808,10 @@ __global__ void __launch_bounds__(RT_SHADE_THREADS) rt_shade(const DScene S, con
         stage_analytic(S, stage);
         setup_rays<true>(S, F, level + 1, in, stage, &fat_n, &slow_n);
     }
+#ifdef RT_STATS
+    ts[5] = clock64();
+    if (lane == 0 && gwave < 8192) for (int k = 0; k < 6; ++k) g_shade_timing[gwave * 8 + k] = ts[k];
+#endif
 }
 
 // color.rs:42-52 + canvas layout.  One thread per local pixel.
