@@ -192,8 +192,9 @@ def main():
     # tables, the longest BVH walk - is paid once for all of them, which matters most for the small shards of many ranks.
     views = args.views_per_pass
     if views <= 0:
-        # as many as make eight 1080p frames' worth of pixels per rank, leaving at least two passes to overlap
-        cap = max(1, min(abi.RT_MAX_VIEWS, 8 * 1920 * 1080 * world // (w * h)))
+        # as many as make sixteen 1080p frames' worth of pixels per rank (the library takes up to 2^25 pixels per pass),
+        # leaving at least two passes to overlap
+        cap = max(1, min(abi.RT_MAX_VIEWS, 16 * 1920 * 1080 * world // (w * h)))
         views = max([v for v in range(1, cap + 1) if args.steps // v >= 2] or [1])
     views = max(1, min(views, abi.RT_MAX_VIEWS, max(args.steps, 1)))
     passes, leftover = divmod(args.steps, views)       # the frames that do not fill a pass get a smaller pass of their own

@@ -696,8 +696,9 @@ static void fill_frame(const RtScene* s, const Geometry& g, uint32_t max_depth, 
 
 static int ensure_frame(RtScene* s, const Geometry& g, uint32_t max_depth, bool aux) {
     const uint32_t blocks = s->list_blocks;
-    // rays one depth may hold (its child rays and the shadow rays of the depth above): 8 per pixel to begin with
-    uint64_t capacity = s->debug_queue_capacity ? s->debug_queue_capacity : (uint64_t)8 * g.n_pixels;
+    // rays one depth may hold (its child rays and the shadow rays of the depth above): 4 per pixel to begin with (the 1080p
+    // bunnies frame needs 0.7 at its fullest depth; a frame that needs more has its lists doubled, see note_overflow)
+    uint64_t capacity = s->debug_queue_capacity ? s->debug_queue_capacity : (uint64_t)4 * g.n_pixels;
     if (const char* env = getenv("RT_QUEUE_CAPACITY")) { long v = atol(env); if (v > 0 && !s->debug_queue_capacity) capacity = (uint64_t)v; }
     capacity <<= s->capacity_shift;
     if (s->must_grow) {
@@ -802,7 +803,7 @@ static int enqueue_frame(RtScene* s, const RtRenderParams* p, bool sharded, bool
     uint32_t blocks = s->list_blocks;
     if (noalloc) {
         if (!s->scratch) return fail(RT_ERR_DEVICE, "rt_render_device_noalloc: device %d has no scratch array", s->device);
-        // one list segment per compute unit, eight rays per pixel and depth, as the handle's own lists start out
+        // one list segment per compute unit, eight rays per pixel and depth (these lists cannot grow)
         blocks = (uint32_t)s->n_cus;
         size_t used = 0;
         auto take = [&](size_t bytes, void** ptr) {
@@ -1044,7 +1045,7 @@ extern "C" int rt_last_kernel_ms(RtScene* s, float out_ms[RT_N_LEVEL_KERNELS], u
     return RT_OK;
 }
 
-// Test aids: the first caps the ray lists of a recursion depth (0 restores the default of eight rays per pixel), the
+// Test aids: the first caps the ray lists of a recursion depth (0 restores the default of four rays per pixel), the
 // second reports how often rt_render had to enlarge the lists and redo its last frame.
 extern "C" int rt_debug_set_queue_capacity(RtScene* s, uint32_t capacity) {
     if (!s) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_set_queue_capacity: null argument");
