@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--cpu-sample-views", type=int, default=4)
-    ap.add_argument("--views-per-pass", type=int, default=8)
+    ap.add_argument("--views-per-pass", type=int, default=16)
     ap.add_argument("--passes-in-flight", type=int, default=3)
     args = ap.parse_args()
 
