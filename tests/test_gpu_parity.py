@@ -249,6 +249,30 @@ def test_instance_grid(tmp_path_factory, grid, n_meshes, level, width, height):
     assert (got["prim_id"] >> 30 == abi.RT_PRIM_MESH_TRIANGLE).sum() > width * height // 20
 
 
+@pytest.mark.parametrize("analytic", ["as in the scene", "none", "too many to stage"])
+def test_instances_scanned_one_by_one(tmp_path_factory, analytic):
+    """Scenes of at most 16 instances scan them one by one: with the culling records staged in LDS next to the analytic
+    primitives (3 x 3 and 4 x 4 grids as they are), and - when there is nothing to stage them next to, or the
+    primitives are too many for LDS - with the boxes read from the instance array.  16 instances is the most this
+    path sees; 17 and more walk the range tree (test_instance_grid)."""
+    from rust_raytracer_amd import synthetic
+    d = str(tmp_path_factory.mktemp("scan_models"))
+    for grid in (3, 4):
+        scene = json.loads(synthetic.instance_grid_scene(d, grid, 3, 2, 240, 135))
+        assert len(scene["mesh_instances"]) == grid * grid <= 16
+        if analytic == "none":
+            scene["planes"], scene["spheres"], scene["triangles"] = [], [], []
+        elif analytic == "too many to stage":
+            material = scene["materials"][0]["name"]
+            scene["spheres"] = scene.get("spheres", []) + [
+                {"center": {"x": -6.0 + 0.013 * k, "y": 3.5 + 0.004 * (k % 50), "z": -14.0 - 0.002 * k}, "radius": 0.02, "material": material}
+                for k in range(900)]
+        s = orc.OracleScene.from_text(json.dumps(scene), d)
+        got, want = render_both(s, max_depth=5)
+        assert_parity(got, want)
+        assert (got["prim_id"] >> 30 == abi.RT_PRIM_MESH_TRIANGLE).sum() > 240 * 135 // 20
+
+
 def test_orbit_views(scenes_dir, model_dir):
     """One uploaded scene, eight camera poses on a circle around it (the batch-of-views configuration at a
     small size): only the camera matrix crosses to the device between frames."""
