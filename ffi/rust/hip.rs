@@ -60,6 +60,7 @@ extern "C" {
     pub fn rt_multi_create(desc: *const RtSceneDesc, device_ids: *const c_int, n_devices: c_int, out: *mut *mut RtMulti) -> c_int;
     pub fn rt_multi_set_camera(m: *mut RtMulti, screen_to_world: *const f32, width: u32, height: u32) -> c_int;
     pub fn rt_multi_render(m: *mut RtMulti, p: *const RtRenderParams, out_pixels: *mut u8) -> c_int;
+    pub fn rt_multi_render_views(m: *mut RtMulti, p: *const RtRenderParams, screen_to_world: *const f32, n_views: u32, views_per_pass: u32, out_pixels: *mut u8) -> c_int;
     pub fn rt_multi_destroy(m: *mut RtMulti);
     pub fn rt_last_error() -> *const c_char;
 }

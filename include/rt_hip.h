@@ -286,21 +286,29 @@ int rt_assemble_shards(RtScene* scene, const RtRenderParams* params, const void*
  * The reference's counterpart is its worker pool: N workers, each with its own copy of the Scene, render interleaved
  * rows into their own buffers and one owner stitches them (web_app/src/main/model.ts:93-129,
  * web_app/wasm/src/renderer.rs:68-76, web_app/src/worker/render_worker.ts:28,48-52).  rt_multi_create replicates the
- * scene on every device of `device_ids` (all different), owns one stream per device and one RCCL communicator set
- * (ncclCommInitAll); rt_multi_render lets device i render the tiles t with t % n_devices == i, moves the shard buffers
- * with one ncclAllGather, assembles the frame on the first device and copies it to `out_pixels` (host memory, the
- * layout of rt_render; with rt_multi_set_views n_views frames back to back).  Shard fields and `stream` of `params`
- * must be unset.  The bytes equal rt_render's for any number of devices.  A frame whose ray lists overflow on some
- * device is rendered again with longer lists, as rt_render does.
- * To rehearse the schedule on a one-GPU machine `device_ids` may name the same device n times: the shards are then
- * rendered one after the other on that GPU and the exchange is device-to-device copies instead of the collective. */
+ * scene on every device of `device_ids` (all different), owns two streams and one issuing host thread per device (the
+ * reference's workers render side by side, render_worker.ts:71-76) and one RCCL communicator set (ncclCommInitAll;
+ * librccl is only loaded for two or more distinct devices); rt_multi_render lets device i render the tiles t with
+ * t % n_devices == i, moves the shard buffers with one ncclAllGather, assembles the frame on the first device and copies
+ * it to `out_pixels` (host memory, the layout of rt_render; with rt_multi_set_views n_views frames back to back).
+ * `stream` of `params` must be NULL, shard_index 0 and shard_count 0 or 1 (RT_ERR_INVALID_ARGUMENT otherwise).  The
+ * bytes equal rt_render's for any number of devices.  A frame whose ray lists overflow on some device is rendered
+ * again with longer lists, as rt_render does.  On any failure every device is waited for before the call returns.
+ * rt_multi_render_views renders `n_views` cameras (matrices back to back, the screen size of the last
+ * rt_multi_set_camera / set_views) in passes of `views_per_pass` (<= RT_MAX_VIEWS) and writes the frames back to back:
+ * exchange, assembly and copy of pass k run on their own streams and buffers while pass k + 1 is traced.  Afterwards the
+ * renderer is back at the views of the last rt_multi_set_views.
+ * To rehearse the schedule on a one-GPU machine `device_ids` may name the same device n times (all entries equal): the
+ * shards then share that GPU and the exchange is device-to-device copies instead of the collective. */
 typedef struct RtMulti RtMulti;
 int rt_multi_create(const RtSceneDesc* desc, const int* device_ids, int n_devices, RtMulti** out_renderer);
 int rt_multi_set_camera(RtMulti* renderer, const float screen_to_world[16], uint32_t width, uint32_t height);
 int rt_multi_set_views(RtMulti* renderer, const float* screen_to_world, uint32_t n_views, uint32_t width, uint32_t height);
 int rt_multi_render(RtMulti* renderer, const RtRenderParams* params, uint8_t* out_pixels);
-/* ray counts of the last frame summed over the devices; wall-clock milliseconds of the last rt_multi_render call
- * (shards, exchange, assembly and the copy to the host) */
+int rt_multi_render_views(RtMulti* renderer, const RtRenderParams* params, const float* screen_to_world, uint32_t n_views,
+                          uint32_t views_per_pass, uint8_t* out_pixels);
+/* ray counts of the last pass summed over the devices; host wall-clock milliseconds of the last rt_multi_render /
+ * rt_multi_render_views call as a whole (shards, exchange, assembly and the copy to the host - not a device time) */
 int rt_multi_last_ray_counts(RtMulti* renderer, uint64_t counters[RT_N_COUNTERS]);
 int rt_multi_last_render_ms(RtMulti* renderer, float* out_ms);
 void rt_multi_destroy(RtMulti* renderer);

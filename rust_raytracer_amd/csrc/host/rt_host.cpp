@@ -350,11 +350,9 @@ struct ObjCursor {
     bool at_eol() const { return p >= end || *p == '\n'; }
     float number() {
         skip_blank();
-        char buf[64];
-        size_t n = 0;
-        while (p < end && n + 1 < sizeof(buf) && *p != ' ' && *p != '\t' && *p != '\r' && *p != '\n') buf[n++] = *p++;
-        buf[n] = 0;
-        return strtof(buf, nullptr);
+        const char* q = p;
+        while (p < end && *p != ' ' && *p != '\t' && *p != '\r' && *p != '\n') ++p;
+        return strtof(std::string(q, (size_t)(p - q)).c_str(), nullptr);
     }
     // An optionally signed decimal integer at p, never reading at or beyond `end` (the buffer need not be
     // NUL-terminated) nor across white space (strtol would skip a line break and take the next line's number).
@@ -526,14 +524,14 @@ struct Json {
         if (word("false")) { nodes[id].type = Bool; return id; }
         if (word("null")) return id;
         // a JSON number, copied out first: the text need not be NUL-terminated and strtod must not read beyond `end`
-        char buf[64];
+        // (the copy is as long as the token: serde_json takes literals of any length, e.g. 0.1000...0 with a hundred digits)
         size_t n = 0;
-        while (p + n < end && n + 1 < sizeof(buf) && (isdigit((unsigned char)p[n]) || p[n] == '-' || p[n] == '+' || p[n] == '.' || p[n] == 'e' || p[n] == 'E')) { buf[n] = p[n]; ++n; }
-        buf[n] = 0;
+        while (p + n < end && (isdigit((unsigned char)p[n]) || p[n] == '-' || p[n] == '+' || p[n] == '.' || p[n] == 'e' || p[n] == 'E')) ++n;
+        const std::string token(p, n);
         char* q = nullptr;
-        double d = strtod(buf, &q);
-        if (q == buf) raise(RT_ERR_PARSE, "scene json: unexpected character");
-        p += q - buf;
+        double d = strtod(token.c_str(), &q);
+        if (q == token.c_str()) raise(RT_ERR_PARSE, "scene json: unexpected character");
+        p += q - token.c_str();
         nodes[id].type = Num;
         nodes[id].num = d;
         return id;

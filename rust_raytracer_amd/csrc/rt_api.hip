@@ -48,6 +48,8 @@ static int scratch_for_device(int device, void** out);
 
 // instance counts above this get a range tree over the culling boxes (rt_setup walks it instead of scanning)
 #define RT_RANGE_TREE_MIN 16
+// the lists of a handle are doubled at most this often (ensure_frame refuses more than 2^30 rays per depth long before)
+#define RT_MAX_CAPACITY_SHIFT 24
 
 struct RtScene {
     int device = 0;
@@ -74,6 +76,7 @@ struct RtScene {
     bool slow_enabled = false;          // rt_setup_slow is launched at every depth
     uint32_t capacity_shift = 0;        // lists are (default capacity << capacity_shift) rays long
     bool must_grow = false;             // a frame overflowed: the next one needs lists longer than it had
+    uint32_t noalloc_seq_lo = 1, noalloc_seq_hi = 0;     // sequence numbers of the latest run of rt_render_device_noalloc frames
     uint32_t walk_contiguous = 0;       // see DFrame::walk_contiguous
     void* scratch = nullptr;            // this device's copy of the static scratch array (rt_render_device_noalloc)
     uint32_t regrown = 0;               // times rt_render had to enlarge the lists for its last frame
@@ -134,6 +137,11 @@ struct MeshLayout {
     uint32_t stack_need4 = 1;        // entries a depth-first walk of that tree can need
     float max_edge_product = 0.0f;   // max |e1| * |e2| over the mesh's triangles
     float max_edge_sum = 0.0f;       // max |e1| + |e2|
+    // Every child box lies inside its parent's box and every triangle inside its leaf's box, as in a tree the
+    // reference's builder makes (each node's box is the hull of its triangles, bvh/builder.rs:100-218).  The distance
+    // pruning of the BVH walk, the culling boxes of rt_setup and the folding of levels all lean on it; a mesh whose
+    // caller-supplied tree breaks it (refitted, loosened, hand-made) is walked without any of them.
+    bool nested = true;
 };
 }  // namespace
 
@@ -155,6 +163,11 @@ static int layout_mesh(const RtSceneDesc* desc, uint32_t mesh_index, std::vector
     uint32_t need = 1;
     const size_t budget = 4 * (size_t)(m.node_end - m.node_begin) + 16;
     auto check_node = [&](uint32_t i) { return i < desc->n_mesh_bvh_nodes; };
+    auto inside = [](const float* lo, const float* hi, const float* outer_lo, const float* outer_hi) {
+        for (int c = 0; c < 3; ++c)
+            if (!(lo[c] >= outer_lo[c] && hi[c] <= outer_hi[c])) return false;          // false for NaN as well
+        return true;
+    };
     while (!stack.empty()) {
         Item it = stack.back();
         stack.pop_back();
@@ -179,6 +192,8 @@ static int layout_mesh(const RtSceneDesc* desc, uint32_t mesh_index, std::vector
                 if (t.material >= desc->n_materials)
                     return fail(RT_ERR_OUT_OF_RANGE, "mesh triangle %u: material %u outside the %u materials", ti, t.material,
                                 desc->n_materials);
+                for (int k3 = 0; k3 < 3; ++k3)
+                    if (!inside(t.vertices[k3], t.vertices[k3], n.aabb_min, n.aabb_max)) out->nested = false;
                 const float* p0 = t.vertices[0];
                 // e1 = p1 - p0, e2 = p2 - p0: the first two operations of Triangle::intersect (intersect.rs:147-148)
                 float e1[3], e2[3];
@@ -203,6 +218,8 @@ static int layout_mesh(const RtSceneDesc* desc, uint32_t mesh_index, std::vector
             ref = (uint32_t)(nodes.size() / 4);
             const RtBvhNode& l = desc->mesh_bvh_nodes[n.child_left];
             const RtBvhNode& r = desc->mesh_bvh_nodes[n.child_right];
+            if (!inside(l.aabb_min, l.aabb_max, n.aabb_min, n.aabb_max) || !inside(r.aabb_min, r.aabb_max, n.aabb_min, n.aabb_max))
+                out->nested = false;
             nodes.push_back(f4(l.aabb_min[0], l.aabb_min[1], l.aabb_min[2], l.aabb_max[0]));
             nodes.push_back(f4(l.aabb_max[1], l.aabb_max[2], r.aabb_min[0], r.aabb_min[1]));
             nodes.push_back(f4(r.aabb_min[2], r.aabb_max[0], r.aabb_max[1], r.aabb_max[2]));
@@ -230,7 +247,10 @@ static int layout_mesh(const RtSceneDesc* desc, uint32_t mesh_index, std::vector
 // entries, each with its box, in the order the reference's walk would reach them (right before left at both levels,
 // intersect.rs:253-256).  A ray passes the box of a folded-away child whenever it passes a box inside it (the slab test
 // of intersect.rs:185-226 is monotone in the box), so a walk of the 4-wide tree tests exactly the leaves the
-// reference's walk tests.  `nodes` is the binary layout of layout_mesh; leaves keep their slots.
+// reference's walk tests.  A child is only folded away when both of its children's boxes do lie inside its own - always,
+// in a tree the reference's builder made; in a tree that breaks the rule such a child stays an entry with its own box
+// (the walk then tests that box as the reference does) and a 4-wide node of its own.
+// `nodes` is the binary layout of layout_mesh; leaves keep their slots.
 static int collapse_mesh(const std::vector<float4>& nodes, uint32_t mesh_index, MeshLayout* ml, std::vector<float4>& nodes4) {
     ml->root_ref4 = ml->root_ref;
     ml->stack_need4 = 1;
@@ -260,6 +280,11 @@ static int collapse_mesh(const std::vector<float4>& nodes, uint32_t mesh_index, 
             if (two[side].ref & RT_REF_LEAF_BIT) { entries[n++] = two[side]; continue; }
             Entry grand[2];
             children(two[side].ref, grand);
+            bool contained = true;
+            for (int g = 0; g < 2; ++g)
+                for (int k = 0; k < 3; ++k)
+                    if (grand[g].ref != RT_REF_NONE && !(grand[g].lo[k] >= two[side].lo[k] && grand[g].hi[k] <= two[side].hi[k])) contained = false;
+            if (!contained) { entries[n++] = two[side]; continue; }             // not folded: the entry leads to the child's own 4-wide node
             for (int g = 0; g < 2; ++g)
                 if (grand[g].ref != RT_REF_NONE) entries[n++] = grand[g];
         }
@@ -439,6 +464,7 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device_id, RtScene**
         o.world_guard = (float)(1.5e-4 * std::sqrt(fro));
         if (!(o.world_guard == o.world_guard) || o.world_guard > 1e30f) o.prunable = 0;
         instance_world_box(in, ml, std::sqrt(fro), &o);
+        if (!ml.nested) { o.prunable = 0; o.cullable = 0; }        // see MeshLayout::nested: every ray takes the exact set-up, walks are not pruned
         if (ml.stack_need > stack_entries) stack_entries = ml.stack_need;
         if (ml.stack_need4 > stack_entries4) stack_entries4 = ml.stack_need4;
     }
@@ -700,6 +726,9 @@ static int ensure_frame(RtScene* s, const Geometry& g, uint32_t max_depth, bool 
     // bunnies frame needs 0.7 at its fullest depth; a frame that needs more has its lists doubled, see note_overflow)
     uint64_t capacity = s->debug_queue_capacity ? s->debug_queue_capacity : (uint64_t)4 * g.n_pixels;
     if (const char* env = getenv("RT_QUEUE_CAPACITY")) { long v = atol(env); if (v > 0 && !s->debug_queue_capacity) capacity = (uint64_t)v; }
+    // doubled once per overflow seen, but never beyond 2^30 rays per depth: a frame that needs more keeps overflowing and is
+    // reported as such, the handle stays usable for smaller frames
+    while (s->capacity_shift > 0 && (s->capacity_shift >= 32 || (capacity << s->capacity_shift) > (1ull << 30))) --s->capacity_shift;
     capacity <<= s->capacity_shift;
     if (s->must_grow) {
         // a frame overflowed the lists it had - which may have been longer than this size asks for (see `fits`)
@@ -780,8 +809,15 @@ static void note_overflow(RtScene* s) {
     if (o != s->overflow_seen) {
         s->overflow_seen = o;
         s->overflow_unreported = true;
-        ++s->capacity_shift;               // the handle's own lists get longer at the next frame
-        s->must_grow = true;
+        // The handle's own lists get longer at the next frame - unless the frame that overflowed was one of
+        // rt_render_device_noalloc, whose lists live in the static scratch and cannot grow: that is reported, nothing more.
+        // (The word names the latest frame that overflowed; a frame of the handle's own lists that overflowed before it in
+        // the same interval makes the next such frame overflow again, and is caught then.)
+        const bool noalloc = o >= s->noalloc_seq_lo && o <= s->noalloc_seq_hi;
+        if (!noalloc) {
+            if (s->capacity_shift < RT_MAX_CAPACITY_SHIFT) ++s->capacity_shift;
+            s->must_grow = true;
+        }
     }
 }
 
@@ -831,6 +867,10 @@ static int enqueue_frame(RtScene* s, const RtRenderParams* p, bool sharded, bool
     f.mode = p->mode;
     if (++s->frame_seq == 0) s->frame_seq = 1;
     f.overflow_seq = s->frame_seq;
+    if (noalloc) {
+        if (s->noalloc_seq_hi + 1 != s->frame_seq || s->noalloc_seq_lo > s->noalloc_seq_hi) s->noalloc_seq_lo = s->frame_seq;
+        s->noalloc_seq_hi = s->frame_seq;
+    }
     if (!aux) { f.aux_flags = f.aux_prim = f.aux_inst = nullptr; f.aux_t = nullptr; }
     HIP_TRY(hipEventRecord(s->ev_start, stream));
     HIP_TRY(hipMemsetAsync(f.acc, 0, sz.pixel_clear_bytes, stream));                              // colour sums + poison words

@@ -1263,9 +1263,15 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
     tm[3] = w_begin;                       // start and end of the wave on the constant 100 MHz clock
 #endif
 
+    // A depth-first walk of any mesh of the scene fits S.stack_entries entries (computed from the trees when the scene was
+    // created).  Should a walk ever ask for more - a corrupted list entry, a tree that is not what was uploaded - the entry
+    // is dropped and the frame flagged like one whose lists overflowed, instead of writing past the stack: the reference's
+    // own walk fails loudly in that place too (ArrayVec::push panics, intersect.rs:240-255).
+    const uint32_t stack_entries = S.stack_entries;
     auto stack_push = [&](uint32_t e, uint32_t ref, float t) {
         if (e < stack_lds) { stack[e * RT_WAVE] = ref; stack_t[e * RT_WAVE] = __float_as_uint(t); }
-        else spill[(e - stack_lds) * spill_lanes] = make_uint2(ref, __float_as_uint(t));
+        else if (e < stack_entries) spill[(e - stack_lds) * spill_lanes] = make_uint2(ref, __float_as_uint(t));
+        else *F.overflow = F.overflow_seq;
     };
 
     for (;;) {
@@ -1527,11 +1533,11 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
                 if (sp < stack_lds) {
                     next_ref = stack[sp * RT_WAVE];
                     next_t = __uint_as_float(stack_t[sp * RT_WAVE]);
-                } else {
+                } else if (sp < stack_entries) {
                     const uint2 e = spill[(sp - stack_lds) * spill_lanes];
                     next_ref = e.x;
                     next_t = __uint_as_float(e.y);
-                }
+                }                                                    // (else: an entry stack_push dropped)
             }
             cur_ref = next_ref; cur_t = next_t;
         }

@@ -18,7 +18,7 @@ EXPORTS = ["rt_scene_create", "rt_scene_set_camera", "rt_scene_set_views", "rt_r
            "rt_assemble_shards", "rt_last_ray_counts", "rt_last_render_ms", "rt_last_trace_ms", "rt_set_kernel_timing",
            "rt_last_kernel_ms", "rt_scene_destroy",
            "rt_debug_set_queue_capacity", "rt_debug_last_regrown", "rt_last_error",
-           "rt_multi_create", "rt_multi_set_camera", "rt_multi_set_views", "rt_multi_render", "rt_multi_last_ray_counts",
+           "rt_multi_create", "rt_multi_set_camera", "rt_multi_set_views", "rt_multi_render", "rt_multi_render_views", "rt_multi_last_ray_counts",
            "rt_multi_last_render_ms", "rt_multi_destroy"]
 # every function include/rt_host.h declares
 HOST_EXPORTS = ["rt_host_scene_parse", "rt_host_scene_load", "rt_host_scene_desc", "rt_host_scene_camera",
@@ -90,6 +90,7 @@ def lib():
         L.rt_multi_set_camera.argtypes = [vp, C.POINTER(C.c_float), u32, u32]
         L.rt_multi_set_views.argtypes = [vp, C.POINTER(C.c_float), u32, u32, u32]
         L.rt_multi_render.argtypes = [vp, C.POINTER(abi.RtRenderParams), vp]
+        L.rt_multi_render_views.argtypes = [vp, C.POINTER(abi.RtRenderParams), C.POINTER(C.c_float), u32, u32, vp]
         L.rt_multi_last_ray_counts.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.rt_multi_last_render_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.rt_multi_destroy.argtypes = [vp]
@@ -274,6 +275,16 @@ class MultiDeviceScene:
         ms = C.c_float()
         check(lib().rt_multi_last_render_ms(self._h, C.byref(ms)))
         return {"rgb": rgb, "counters": np.array(c, dtype=np.uint64), "ms": float(ms.value)}
+
+    def render_views(self, screen_to_world, views_per_pass: int, max_depth: int = 10, channels: int = 3):
+        """rt_multi_render_views: any number of cameras at the current screen size, `views_per_pass` at a time, the
+        exchange of one pass overlapped with the tracing of the next.  Returns the frames [n, H, W, channels]."""
+        m = np.ascontiguousarray(np.asarray(screen_to_world, dtype=np.float32).reshape(-1, 16))
+        rgb = np.zeros((m.shape[0], self.height, self.width, channels), dtype=np.uint8)
+        p = abi.RtRenderParams(max_depth, abi.RT_FORMAT_RGBA8 if channels == 4 else abi.RT_FORMAT_RGB8, 0, 0, 0, 0, None)
+        check(lib().rt_multi_render_views(self._h, C.byref(p), m.ctypes.data_as(C.POINTER(C.c_float)), m.shape[0], views_per_pass,
+                                          rgb.ctypes.data_as(C.c_void_p)))
+        return rgb
 
 
 def write_png(path: str, pixels: np.ndarray):

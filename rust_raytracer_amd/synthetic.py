@@ -216,6 +216,105 @@ def spoiled_scene(model_dir: str, seed: int, width: int = 96, height: int = 64):
     return json.dumps(scene), done
 
 
+def mixed_scene(model_dir: str, seed: int):
+    """spoiled_scene(seed) pushed further, everything at once: orthographic cameras and fields of view of 1 to 180 degrees,
+    light positions with w = 2, -1, 1e-3, instances 1e3 .. 1e5 away or scaled by 1e-3 / 1e3, and (half of the scenes) a
+    second mesh made of a triangle soup (1 to 200 triangles from 1e-3 to 1.5 units, exact duplicates, collapsed
+    triangles) instanced one to four times, now and then scaled to zero along an axis.  The first mesh of such a scene
+    is deeper than a soup: a ray traced on the exact path (singular matrices) in a frame that also walks soups is what
+    once made the BVH walk treat a result-only list entry as a walk item.
+    Returns (scene JSON, recursion depth to render with, list of what was done)."""
+    import random
+    rng = random.Random(seed * 86028121 + 17)
+    u = rng.uniform
+    w, h = rng.choice([(96, 64), (33, 31), (130, 70), (64, 8)])
+    text, what = spoiled_scene(model_dir, seed, w, h)
+    scene = json.loads(text)
+    cam = scene["camera"]
+    if rng.random() < 0.25:
+        cam["use_perspective"] = False
+        cam["ortho_world_height"] = rng.choice([0.5, 10, 200])
+        what.append("ortho")
+    if rng.random() < 0.15:
+        cam["y_fov_degrees"] = rng.choice([1.0, 150.0, 178.0, 180.0])
+        what.append("fov")
+    for light in scene["lights"]:
+        if rng.random() < 0.25:
+            light["position"]["w"] = rng.choice([2.0, -1.0, 1e-3])
+            what.append("light w")
+    for inst in scene["mesh_instances"]:
+        r = rng.random()
+        if r < 0.1:
+            k = rng.choice([1e3, 1e5])
+            inst["position"] = {c: inst["position"][c] * k for c in "xyz"}
+            what.append("far")
+        elif r < 0.2:
+            k = rng.choice([1e-3, 1e3])
+            inst["scale"] = {c: inst["scale"][c] * k for c in "xyz"}
+            what.append("scale %g" % k)
+    if rng.random() < 0.5:
+        n = rng.choice([1, 6, 40, 200])
+        size = rng.choice([1e-3, 0.05, 0.3, 1.5])
+        lines, tris = [], []
+        for k in range(n):
+            c = (u(-1, 1), u(-1, 1), u(-1, 1))
+            r = rng.random()
+            if r < 0.1 and tris:
+                tri = list(tris[rng.randrange(len(tris))])
+            elif r < 0.2:
+                p = [c[i] + u(-size, size) for i in range(3)]
+                tri = [p, p, [c[i] + u(-size, size) for i in range(3)]]
+            else:
+                tri = [[c[i] + u(-size, size) for i in range(3)] for _ in range(3)]
+            tris.append(tri)
+        for tri in tris:
+            for p in tri:
+                lines.append("v %.6f %.6f %.6f" % tuple(p))
+        for k in range(len(tris)):
+            nn = (u(-1, 1), u(-1, 1), u(0.2, 1))
+            for _ in range(3):
+                lines.append("vn %.6f %.6f %.6f" % nn)
+        for k in range(len(tris)):
+            i = 3 * k + 1
+            lines.append("f %d//%d %d//%d %d//%d" % (i, i, i + 1, i + 1, i + 2, i + 2))
+        with open(os.path.join(model_dir, "soup.obj"), "w") as fh:
+            fh.write("\n".join(lines) + "\n")
+        opaque = [m["name"] for m in scene["materials"] if isinstance(m["material_type"], str)]
+        scene["meshes"].append({"name": "soup", "file_name": "soup.obj", "winding_order": rng.choice(["Clockwise", "CounterClockwise"]),
+                                "material": rng.choice(opaque)})
+        for _ in range(rng.randint(1, 4)):
+            scene["mesh_instances"].insert(rng.randrange(len(scene["mesh_instances"]) + 1), {
+                "mesh": "soup", "position": _xyz(u(-3, 3), u(-1, 3), u(-9, -3)), "orientation_degrees": _xyz(u(0, 360), u(0, 360), u(0, 360)),
+                "scale": _xyz(rng.choice([0.0, u(0.2, 2)]) if rng.random() < 0.1 else u(0.2, 2), u(0.2, 2), u(0.2, 2))})
+        what.append("soup %d" % n)
+    depth = rng.choice([1, 3, 5, 8])
+    return json.dumps(scene), depth, what
+
+
+def shrink_bvh_boxes(desc, every: int = 3, which: int = 1) -> int:
+    """Spoils the BVH of a scene description in place: the box of every node whose index is `which` modulo `every`
+    (inner nodes and leaves alike) loses a quarter of its extent on both sides of every axis, in float32 arithmetic
+    (lo + (hi - lo) * 0.25, hi - (hi - lo) * 0.25).  Child boxes then stick out of their parents' and triangles out of
+    their leaves' - a tree no builder made, as a caller may still hand one over; the reference tests every box as it
+    is (intersect.rs:245-250).  tests/emu/emu_render does the same under EMU_SHRINK_BVH=1.  Returns the number of
+    nodes changed."""
+    import ctypes as C
+
+    import numpy as np
+    n = desc.n_mesh_bvh_nodes
+    if n == 0:
+        return 0
+    words = C.sizeof(desc.mesh_bvh_nodes._type_) // 4
+    raw = np.ctypeslib.as_array(C.cast(desc.mesh_bvh_nodes, C.POINTER(C.c_float)), shape=(n, words))
+    idx = np.arange(n)[np.arange(n) % every == which]
+    lo, hi = raw[idx, 0:3].copy(), raw[idx, 3:6].copy()
+    w = (hi - lo).astype(np.float32)
+    q = (w * np.float32(0.25)).astype(np.float32)
+    raw[idx, 0:3] = (lo + q).astype(np.float32)
+    raw[idx, 3:6] = (hi - q).astype(np.float32)
+    return len(idx)
+
+
 def pruning_stress_scene(model_dir: str, seed: int = 0):
     """A scene built to sit on the edges of the BVH walk's distance pruning (the walk may only skip what cannot win):
 

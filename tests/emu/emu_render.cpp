@@ -37,6 +37,20 @@ int main(int argc, char** argv) {
         RtSceneDesc desc_value;
         rt_host_scene_desc(host, &desc_value);
         const RtSceneDesc* desc = &desc_value;
+        if (getenv("EMU_SHRINK_BVH")) {
+            // spoils the tree in place, as synthetic.shrink_bvh_boxes does: every third node's box loses a quarter of its extent
+            // on both sides, so child boxes stick out of their parents' and triangles out of their leaves'
+            RtBvhNode* nodes = const_cast<RtBvhNode*>(desc->mesh_bvh_nodes);
+            for (uint32_t i = 0; i < desc->n_mesh_bvh_nodes; ++i) {
+                if (i % 3 != 1) continue;
+                for (int c = 0; c < 3; ++c) {
+                    const float w = nodes[i].aabb_max[c] - nodes[i].aabb_min[c];
+                    const float q = w * 0.25f;
+                    nodes[i].aabb_min[c] = nodes[i].aabb_min[c] + q;
+                    nodes[i].aabb_max[c] = nodes[i].aabb_max[c] - q;
+                }
+            }
+        }
         RtScene* scene = nullptr;
         if (rt_scene_create(desc, 0, &scene) != RT_OK) { fprintf(stderr, "%s: create: %s\n", path, rt_last_error()); rt_host_scene_destroy(host); ++failures; continue; }
         float m[16]; uint32_t w = 0, h = 0;

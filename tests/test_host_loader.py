@@ -120,6 +120,29 @@ def test_loader_errors_are_reported(scenes_dir, tmp_path):
     assert scene.desc().n_mesh_triangles == 0
 
 
+def test_long_number_literals(scenes_dir):
+    """serde_json takes number literals of any length (scene_file/parser.rs:62); a literal of a hundred digits must parse
+    to the same arrays as its short spelling, not be cut off."""
+    text = open(os.path.join(scenes_dir, "cornell_box.json")).read()
+    scene = json.loads(text)
+    radius = scene["spheres"][0]["radius"]
+    short = json.dumps(scene)
+    marker = "\"radius\": %s" % json.dumps(radius)
+    assert short.count(marker) >= 1
+    long_literal = ("%.1f" % radius if float(radius).is_integer() else repr(float(radius))) + "0" * 100
+    assert float(long_literal) == float(radius) and len(long_literal) > 100
+    a = native.HostScene.parse(short)
+    b = native.HostScene.parse(short.replace(marker, "\"radius\": " + long_literal, 1))
+    try:
+        da, db = a.desc(), b.desc()
+        assert da.n_spheres == db.n_spheres > 0
+        n = C.sizeof(abi.RtSphere) * da.n_spheres
+        assert C.string_at(da.spheres, n) == C.string_at(db.spheres, n)
+    finally:
+        a.close()
+        b.close()
+
+
 def test_exports_match_headers():
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

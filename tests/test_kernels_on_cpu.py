@@ -32,18 +32,22 @@ def emu_render():
     return os.path.join(EMU, "emu_render")
 
 
-def render_and_compare(emu_render, scene_text, model_dir, work, max_depth, queue_capacity=0):
+def render_and_compare(emu_render, scene_text, model_dir, work, max_depth, queue_capacity=0, shrink_bvh=False):
     path = os.path.join(work, "scene.json")
     with open(path, "w") as f:
         f.write(scene_text)
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
     if queue_capacity:
         env["EMU_QUEUE_CAPACITY"] = str(queue_capacity)
+    if shrink_bvh:
+        env["EMU_SHRINK_BVH"] = "1"
     out = os.path.join(work, "out")
     r = subprocess.run([emu_render, model_dir, str(max_depth), path, out], capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stderr[-4000:]                       # a sanitizer report ends up here
     s = orc.OracleScene.from_text(scene_text, model_dir)
     try:
+        if shrink_bvh:
+            assert synthetic.shrink_bvh_boxes(s.desc()) > 0           # the oracle's own arrays, in place
         want = s.render(max_depth=max_depth)
     finally:
         s.close()
@@ -91,6 +95,41 @@ def test_generated_scenes(emu_render, tmp_path):
         work.mkdir()
         render_and_compare(emu_render, text, d, str(work), 4)
     assert "zero scale" in seen or "duplicate instance" in seen, seen
+
+
+def test_result_only_entries_are_not_walked(emu_render, tmp_path):
+    """A frame that faulted the GPU once: in synthetic.mixed_scene(9019) rays are traced on the exact path (which
+    leaves list entries that only record a result) and the meshes the scene instances - a triangle soup among them -
+    have shallower trees than the scene's first mesh.  A walk that takes such an entry for a walk item walks the first
+    mesh with a null ray that passes every box, on a stack sized for the meshes the scene instances: the sanitizer
+    stops at the push.  (The reference's own walk panics in the same place when its 32 entries are exceeded,
+    intersect.rs:240-255.)  Neighbouring seeds of the generator ride along."""
+    d = str(tmp_path)
+    for seed in (9019, 9020, 9023):
+        work = tmp_path / ("mixed%d" % seed)
+        work.mkdir()
+        text, depth, what = synthetic.mixed_scene(d, seed)
+        if seed == 9019:
+            assert any(x.startswith("soup") for x in what), what
+        render_and_compare(emu_render, text, d, str(work), depth)
+
+
+def test_tree_whose_boxes_do_not_nest(emu_render, scenes_dir, model_dir, tmp_path):
+    """A caller-supplied BVH need not be one a builder made.  With every third node's box shrunk, child boxes stick out of
+    their parents' and triangles out of their leaves'; the reference tests every box as it stands (intersect.rs:245-250)
+    and so skips subtrees a nested tree would not.  The library must then neither fold such a level away (it would test
+    the grandchildren's boxes only) nor prune by distance or cull by the root box: the picture is the oracle's on the
+    same spoiled tree, and not the one of the intact tree."""
+    text = small(scenes_dir, "reflective_bunnies", 72, 40)
+    work = tmp_path / "shrunk"
+    work.mkdir()
+    render_and_compare(emu_render, text, model_dir, str(work), 4, shrink_bvh=True)
+    intact = tmp_path / "intact"
+    intact.mkdir()
+    render_and_compare(emu_render, text, model_dir, str(intact), 4)
+    a = np.fromfile(str(work / "out.prim"), dtype=np.uint32)
+    b = np.fromfile(str(intact / "out.prim"), dtype=np.uint32)
+    assert (a != b).sum() > 20                                        # the spoiled boxes do change what is hit
 
 
 def test_other_entry_points(emu_render, scenes_dir, model_dir, tmp_path):
