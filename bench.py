@@ -17,6 +17,15 @@ frames of a pass trace the same rays; `value` counts the rays of the frames actu
 exactly --steps frames is repeated --repeats times and the median is reported.  The "sequential" object of the JSON
 line is the rate with one frame at a time at the scene's own camera.
 
+`roofline` describes the mode `value` is timed in: the per-kernel durations come from passes of --views-per-pass frames
+(HIP events around every launch, one pass at a time, outside the timed region), the kernel with the largest share there
+is the one reported, the other per-depth kernel stands beside it (`roofline.other`), and what the same kernels take with
+one frame at a time is kept under `roofline.one_frame_at_a_time`.
+
+--exercise-collective (with --gpus 1): the single rank initialises the RCCL process group and sends every pass through
+the real all_gather_into_tensor and the assemble step, so that the N > 1 branch runs on a one-GPU box (its bytes checked
+against frames rendered without it); not a measurement of scaling.
+
 Rank 0 prints one JSON line.  The scene's bunny.obj is not part of the reference repository; a
 deterministic stand-in of 81 920 triangles is generated (rust_raytracer_amd/meshes.py) unless a real
 bunny.obj is found in --model-dir.
@@ -127,6 +136,8 @@ def main():
     ap.add_argument("--same-camera", action="store_true", help="every frame in flight uses the scene's own camera (as an earlier version of this benchmark did)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="all ranks share cuda:0 and gather over gloo: checks the N>1 code path on a one-GPU box, not a measurement")
+    ap.add_argument("--exercise-collective", action="store_true",
+                    help="with --gpus 1: initialise the RCCL process group (world size 1) and send every pass through all_gather_into_tensor + assemble")
     ap.add_argument("--watchdog", type=int, default=900, help="seconds after which a stuck run prints its stacks and exits non-zero (0 = off)")
     args = ap.parse_args()
     if args.watchdog:
@@ -155,6 +166,11 @@ def main():
         dist.init_process_group("gloo", rank=rank, world_size=world)
     elif world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    elif args.exercise_collective:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+    collective = world > 1 or args.exercise_collective
 
     scene_file, width, height, max_depth = WORKLOADS[args.workload]
     model_dir = args.model_dir
@@ -226,7 +242,7 @@ def main():
     class Slot:
         """One pass in flight: a scene handle (own ray lists), a stream and the buffers of its frames, one per camera."""
 
-        def __init__(self, cams, dev=None, stream=None):
+        def __init__(self, cams, dev=None, stream=None, gather=True):
             self.views = len(cams)
             self.cams = cams
             self.dev = dev or native.DeviceScene(host.desc(), local_rank)
@@ -242,7 +258,8 @@ def main():
                 dev.assemble_shards(gathered.data_ptr(), frame.data_ptr(), world, stream=handle)
 
             self.sf = sharding.ShardedFrame(w, h, 3, rank, world, "cuda", render_shard, assemble,
-                                            host_staged_gather if args.rehearse_on_one_gpu else None, views=self.views)
+                                            host_staged_gather if args.rehearse_on_one_gpu else None, views=self.views,
+                                            always_gather=args.exercise_collective and world == 1 and gather)
 
         def step(self):
             with torch.cuda.stream(self.stream):       # the all-gather orders itself against torch's current stream
@@ -302,7 +319,22 @@ def main():
 
     # The same number of frames one at a time on one handle and one stream, at the scene's own camera, for the latency
     # of a single frame; the per-kernel pass further down runs this way too, so that a launch's duration is its own.
-    one = Slot(cameras[:1], dev=dev, stream=slots[0].stream)       # slot 0's handle, from here on with a single view
+    # Per-kernel durations in the mode `value` is timed in: passes of `views` frames on slot 0's handle, every launch of the
+    # per-depth kernels bracketed by HIP events on the launch stream, one pass at a time (outside the timed region above, so
+    # that the event records do not touch `value`).
+    dev.set_kernel_timing(True)
+    pass_kernel_ms = {k: [0.0, 0] for k in dev.LEVEL_KERNELS}
+    timing_passes = max(2, min(8, -(-args.steps // views)))
+    for _ in range(timing_passes):
+        slots[0].step()
+        for k, (ms, n) in dev.last_kernel_ms().items():        # waits for this pass's last event
+            pass_kernel_ms[k][0] += ms
+            pass_kernel_ms[k][1] += n
+    dev.set_kernel_timing(False)
+    pass_counts = dev.last_ray_counts().astype(np.int64)           # this rank's share of one pass (all of its views)
+    barrier()
+
+    one = Slot(cameras[:1], dev=dev, stream=slots[0].stream, gather=False)       # slot 0's handle, from here on with a single view
     one.step(); one.step()
     sequential = []
     for _ in range(3):
@@ -360,10 +392,97 @@ def main():
     elapsed, elapsed_sequential = (float(x) for x in t.cpu())
     rays = rays.cpu().numpy()
     region_rays, frame_rays = rays[:5], rays[5:10]
-    # the roofline is that of THIS rank's launches: its own shard's rays and walk work, not the frame's
-    shard_rays = [int(x) for x in own_counts[:5]]
-    walk_nodes, walk_tris = int(own_counts[abi.RT_CTR_WALK_NODE_VISITS]), int(own_counts[abi.RT_CTR_WALK_TRIANGLE_TESTS])
+    # (the roofline below is that of THIS rank's launches: its own shard's rays and walk work, not the frame's)
 
+    # ---- roofline: the per-depth kernel with the largest share of a frame in the mode `value` is timed in (passes of
+    # `views` frames), the other per-depth kernel beside it, and both again for one frame at a time ----
+    traffic_file = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+    traffic_table = json.load(open(traffic_file)).get("kernels", {}) if os.path.exists(traffic_file) and world == 1 else {}
+    queued_traffic_file = os.path.join(ROOT, "profiles", "traffic_queued_%s.json" % args.workload)
+    queued_traffic = json.load(open(queued_traffic_file)) if os.path.exists(queued_traffic_file) and world == 1 else {}
+
+    def kernel_roofline(name, times, frames_per_launch, work_counts, hbm_bytes_per_launch, ref_work=None):
+        """Roofline object of kernel `name`: `times` = {kernel: [summed ms, launches]} over launches that each handle
+        `frames_per_launch` frames' worth of this rank's rays, `work_counts` = the counters of one such set of launches
+        (one pass, or one frame)."""
+        ms_sum, launches = times[name]
+        if not launches:
+            return None
+        per_set = launches // max(n_sets[id(times)], 1)     # launches per pass / per frame
+        seconds = ms_sum / launches * 1e-3
+        r = {"kernel": name, "launches_per_pass": per_set, "frames_per_launch": frames_per_launch, "avg_launch_ms": ms_sum / launches,
+             "ms_per_frame": ms_sum / n_sets[id(times)] / frames_per_launch, "traffic": hbm_bytes_per_launch}
+        hbm = {"achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+               "what": "HBM-side bytes per launch from the PMC counters (profiles/traffic_*%s.json) / the launch's duration" % args.workload}
+        if hbm_bytes_per_launch:
+            hbm["achieved"] = hbm_bytes_per_launch / seconds / 1e9
+            hbm["frac"] = hbm["achieved"] / HBM_PEAK_GBS
+        rays_of_set = max(int(work_counts[0]), 1)
+        if name == "rt_traverse":
+            # the kernel's own counted work: the nodes its pruned walk visited (four box tests each) and the triangle tests it ran
+            nodes, tris = int(work_counts[abi.RT_CTR_WALK_NODE_VISITS]), int(work_counts[abi.RT_CTR_WALK_TRIANGLE_TESTS])
+            flops = FLOPS_PER_BOX_TEST * BOXES_PER_NODE_VISIT * nodes + FLOPS_PER_TRIANGLE_TEST * tris
+            achieved = flops / per_set / seconds / 1e12
+            r.update({"bound": "valu", "achieved": achieved, "peak": FP32_NO_FMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                      "frac": achieved / FP32_NO_FMA_PEAK_TFLOPS,
+                      "work": {"node_visits": nodes, "triangle_tests": tris, "flops": flops, "flops_per_ray": flops / rays_of_set,
+                               "per": "pass of %d frames" % frames_per_launch if frames_per_launch > 1 else "frame",
+                               "counted_by": "the kernel itself (RT_CTR_WALK_*), %d flop per box test x %d boxes per node visit, "
+                                             "%d per triangle test" % (FLOPS_PER_BOX_TEST, BOXES_PER_NODE_VISIT, FLOPS_PER_TRIANGLE_TEST)},
+                      "hbm": hbm})
+            if ref_work is not None:
+                # for comparison only: the rate the reference's un-pruned walk would need to finish in the same time
+                r["reference_equivalent"] = {
+                    "GBs": ref_work["bytes"] * frames_per_launch / per_set / seconds / 1e9,
+                    "TFLOPs": ref_work["flops"] * frames_per_launch / per_set / seconds / 1e12,
+                    "what": "bytes and flops of the reference's UN-PRUNED walk (oracle-counted, the scene's own camera) / this kernel's "
+                            "time: an equivalent rate, not work done and no roofline fraction"}
+        else:
+            nbytes = list_kernel_bytes([int(x) for x in work_counts[:5]], n_lights, times["rt_setup"][1], times["rt_shade"][1])[name]
+            achieved = nbytes / per_set / seconds / 1e9
+            r.update({"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                      "work": {"bytes": nbytes, "bytes_per_ray": nbytes / rays_of_set,
+                               "per": "pass of %d frames" % frames_per_launch if frames_per_launch > 1 else "frame",
+                               "counted_by": "record sizes x the ray counts (list_kernel_bytes in bench.py)"},
+                      "measured_hbm": hbm})
+        return r
+
+    n_sets = {id(pass_kernel_ms): timing_passes, id(kernel_ms): max(args.steps, 1)}
+    # rank 0 of a single-GPU run also times the CPU oracle, whose counters give the reference's un-pruned walk work
+    baseline, ref_counters = None, None
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        baseline, ref_counters = cpu_baseline(scene_path, model_dir, w, h, max_depth)
+    ref_work = reference_walk_work(ref_counters) if ref_counters is not None else None
+
+    def queued_hbm(name):
+        # PMC traffic of a pass of `views` frames, collected per launch on passes of queued_traffic["views"] frames
+        k = queued_traffic.get("kernels", {}).get(name)
+        return k["hbm_bytes_per_launch"] / queued_traffic["views"] * views if k else None
+
+    queued = {k: kernel_roofline(k, pass_kernel_ms, views, pass_counts, queued_hbm(k), ref_work) for k in ("rt_traverse", "rt_shade", "rt_setup")}
+    alone = {k: kernel_roofline(k, kernel_ms, 1, own_counts, traffic_table.get(k, {}).get("hbm_bytes_per_launch"), ref_work)
+             for k in ("rt_traverse", "rt_shade", "rt_setup")}
+    queued = {k: v for k, v in queued.items() if v}
+    alone = {k: v for k, v in alone.items() if v}
+    dominant = max(queued, key=lambda k: queued[k]["ms_per_frame"])
+    roofline = dict(queued[dominant])
+    roofline["mode"] = "passes of %d frames, one pass at a time: the mode `value` is timed in (there with %d passes in flight)" % (views, depth)
+    roofline["scope"] = "the whole frame" if world == 1 else "rank %d's launches: its 1/%d shard of every frame (work counted on that shard)" % (rank, world)
+    roofline["kernels_ms_per_frame"] = {k: v["ms_per_frame"] for k, v in queued.items()}
+    others = sorted((k for k in queued if k != dominant), key=lambda k: -queued[k]["ms_per_frame"])
+    if others:
+        roofline["other"] = queued[others[0]]
+    alone_dominant = max(alone, key=lambda k: alone[k]["ms_per_frame"]) if alone else None
+    roofline["one_frame_at_a_time"] = {"kernels_ms_per_frame": {k: v["ms_per_frame"] for k, v in alone.items()},
+                                       "trace_ms_per_frame": trace_ms, "frame_kernel_ms": frame_ms,
+                                       "dominant": alone.get(alone_dominant)}
+    # every rank's own line of the same table (a rank's launches handle its own shard)
+    mine = {"rank": rank, "kernel": roofline["kernel"], "bound": roofline["bound"], "achieved": roofline["achieved"], "unit": roofline["unit"],
+            "frac": roofline["frac"], "avg_launch_ms": roofline["avg_launch_ms"], "kernels_ms_per_frame": roofline["kernels_ms_per_frame"]}
+    per_rank = [mine]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     if rank == 0:
         rays_per_frame = int(frame_rays[0])
         value = int(region_rays[0]) / elapsed / 1e6
@@ -386,65 +505,22 @@ def main():
                        "reflected": int(frame_rays[3]), "transmitted": int(frame_rays[4]),
                        "frames_in_flight": depth * views, "passes_in_flight": depth, "views_per_pass": views,
                        "parallelism": ("tile-sharded x%d, scene replicated, %s" % (world, "REHEARSAL: ranks share one GPU, gloo"
-                                       if args.rehearse_on_one_gpu else "RCCL all-gather")) if world > 1 else "single GPU"},
+                                       if args.rehearse_on_one_gpu else "RCCL all-gather")) if world > 1 else
+                                      ("single GPU, every pass through an RCCL all-gather of world size 1" if args.exercise_collective else "single GPU")},
             # one frame at a time at the scene's own camera (the next is issued behind the previous one on the same stream)
             "sequential": {"value": rays_per_frame * args.steps / elapsed_sequential / 1e6, "unit": "Mrays/s",
                            "ms_per_step": elapsed_sequential / args.steps * 1e3},
         }
-        ref_counters = None
-        if not args.no_cpu_baseline and world == 1:
-            baseline, ref_counters = cpu_baseline(scene_path, model_dir, w, h, max_depth)
+        if baseline is not None:
             out["cpu_baseline"] = baseline
             # the frame the GPU produced must agree with the oracle's ray statistics
             assert [int(x) for x in ref_counters[:5]] == [int(x) for x in frame_rays], "ray counts differ from the oracle"
 
-        # ---- roofline of the dominant kernel: the per-depth kernel with the largest share of a frame rendered alone ----
-        per_frame_ms = {k: (v[0] / args.steps if args.steps else 0.0) for k, v in kernel_ms.items()}
-        dominant = max(per_frame_ms, key=per_frame_ms.get)
-        ms_sum, launches = kernel_ms[dominant]
-        per_frame_launches = launches // args.steps if args.steps else 0
-        avg_launch_ms = ms_sum / launches if launches else None
-        traffic_file = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
-        traffic = None
-        if os.path.exists(traffic_file) and world == 1:                 # the counters were collected on whole frames of one GPU
-            traffic = json.load(open(traffic_file)).get("kernels", {}).get(dominant, {}).get("hbm_bytes_per_launch")
-        roofline = {"kernel": dominant, "launches_per_frame": per_frame_launches, "avg_launch_ms": avg_launch_ms,
-                    "scope": "the whole frame" if world == 1 else "rank 0's launches: its 1/%d shard of the frame (work counted on that shard)" % world,
-                    "kernels_ms_per_frame": per_frame_ms, "trace_ms_per_frame": trace_ms, "frame_kernel_ms": frame_ms,
-                    "traffic": traffic}
-        if launches:
-            seconds = avg_launch_ms * 1e-3
-            hbm = {"achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
-                   "what": "HBM-side bytes per launch from the PMC counters (profiles/traffic_%s.json) / the launch's duration" % args.workload}
-            if traffic:
-                hbm["achieved"] = traffic / seconds / 1e9
-                hbm["frac"] = hbm["achieved"] / HBM_PEAK_GBS
-            if dominant == "rt_traverse":
-                # the kernel's own counted work: the nodes its pruned walk visited (four box tests each) and the triangle tests it ran
-                flops = FLOPS_PER_BOX_TEST * BOXES_PER_NODE_VISIT * walk_nodes + FLOPS_PER_TRIANGLE_TEST * walk_tris
-                achieved = flops / per_frame_launches / seconds / 1e12
-                roofline.update({"bound": "valu", "achieved": achieved, "peak": FP32_NO_FMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                 "frac": achieved / FP32_NO_FMA_PEAK_TFLOPS,
-                                 "work": {"node_visits_per_frame": walk_nodes, "triangle_tests_per_frame": walk_tris,
-                                          "flops_per_frame": flops, "flops_per_ray": flops / max(shard_rays[0], 1),
-                                          "counted_by": "the kernel itself (RT_CTR_WALK_*), %d flop per box test x %d boxes per node visit, "
-                                                        "%d per triangle test" % (FLOPS_PER_BOX_TEST, BOXES_PER_NODE_VISIT, FLOPS_PER_TRIANGLE_TEST)},
-                                 "hbm": hbm})
-                if ref_counters is not None:
-                    # for comparison only: the rate the reference's un-pruned walk would need to finish in the same time
-                    ref = reference_walk_work(ref_counters)
-                    roofline["reference_equivalent"] = {
-                        "GBs": ref["bytes"] / per_frame_launches / seconds / 1e9, "TFLOPs": ref["flops"] / per_frame_launches / seconds / 1e12,
-                        "what": "bytes and flops of the reference's UN-PRUNED walk (oracle-counted) / this kernel's time: an equivalent "
-                                "rate, not work done and no roofline fraction"}
-            else:
-                nbytes = list_kernel_bytes(shard_rays, n_lights, kernel_ms["rt_setup"][1], kernel_ms["rt_shade"][1])[dominant]
-                achieved = nbytes / per_frame_launches / seconds / 1e9
-                roofline.update({"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                                 "work": {"bytes_per_frame": nbytes, "bytes_per_ray": nbytes / max(shard_rays[0], 1),
-                                          "counted_by": "record sizes x the frame's ray counts (list_kernel_bytes in bench.py)"},
-                                 "measured_hbm": hbm})
         out["roofline"] = roofline
+        if world > 1:
+            out["roofline_per_rank"] = per_rank
+        if args.exercise_collective:
+            out["collective_exercised"] = "every pass of the timed region went through all_gather_into_tensor on an RCCL process group of world size %d and the assemble step" % world
         out["frame_checksum"] = int(np.asarray(frame_check, dtype=np.uint64).sum())
         print(json.dumps(out))
     for s in every_slot:

@@ -187,6 +187,9 @@ enum {
      * tests it ran; no counterpart in the reference's walk, which the five counters above describe */
     RT_CTR_WALK_NODE_VISITS,
     RT_CTR_WALK_TRIANGLE_TESTS,
+    /* (ray, instance) pairs whose ray enters the mesh so far out that it passes nearly every box: tested against every
+     * leaf by a block of their own instead of being walked (their box and triangle tests are in the two counters above) */
+    RT_CTR_WALK_HEAVY_PAIRS,
     RT_N_COUNTERS
 };
 

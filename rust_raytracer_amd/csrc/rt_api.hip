@@ -142,6 +142,7 @@ struct MeshLayout {
     // pruning of the BVH walk, the culling boxes of rt_setup and the folding of levels all lean on it; a mesh whose
     // caller-supplied tree breaks it (refitted, loosened, hand-made) is walked without any of them.
     bool nested = true;
+    uint32_t leaf_begin = 0, leaf_count = 0;     // the mesh's leaves in DScene::leaf_boxes (reference visiting order)
 };
 }  // namespace
 
@@ -150,12 +151,13 @@ struct MeshLayout {
 // triangles of each leaf get consecutive slots in that order - so a lower slot means "visited earlier
 // by the reference", which is what decides ties there (utils/mod.rs:17).
 static int layout_mesh(const RtSceneDesc* desc, uint32_t mesh_index, std::vector<float4>& nodes, std::vector<float4>& hot,
-                       std::vector<float4>& cold, MeshLayout* out) {
+                       std::vector<float4>& cold, std::vector<float4>& leaf_boxes, MeshLayout* out) {
     const RtMesh& m = desc->meshes[mesh_index];
     if (m.node_begin > m.node_end || m.node_end > desc->n_mesh_bvh_nodes)
         return fail(RT_ERR_OUT_OF_RANGE, "mesh %u: node range [%u, %u) outside the %u nodes", mesh_index, m.node_begin,
                     m.node_end, desc->n_mesh_bvh_nodes);
     if (m.node_begin == m.node_end) return RT_OK;            // empty BVH: never hit (intersect.rs:235-237)
+    out->leaf_begin = (uint32_t)(leaf_boxes.size() / 2);
     struct Item { uint32_t src; uint32_t parent; bool right; uint32_t depth; };
     std::vector<Item> stack;
     stack.push_back({m.node_begin, 0xFFFFFFFFu, false, 0});
@@ -211,6 +213,10 @@ static int layout_mesh(const RtSceneDesc* desc, uint32_t mesh_index, std::vector
                 if (!(sum <= out->max_edge_sum)) out->max_edge_sum = sum;
             }
             ref = RT_REF_LEAF_BIT | (n.triangle_count << RT_REF_COUNT_SHIFT) | (uint32_t)first;
+            if (n.triangle_count) {
+                leaf_boxes.push_back(f4(n.aabb_min[0], n.aabb_min[1], n.aabb_min[2], n.aabb_max[0]));
+                leaf_boxes.push_back(f4(n.aabb_max[1], n.aabb_max[2], bits(ref), 0.0f));
+            }
         } else {
             if (!check_node(n.child_left) || !check_node(n.child_right))
                 return fail(RT_ERR_OUT_OF_RANGE, "mesh %u: node %u has a child outside the %u nodes", mesh_index, it.src,
@@ -239,6 +245,7 @@ static int layout_mesh(const RtSceneDesc* desc, uint32_t mesh_index, std::vector
         }
     }
     out->stack_need = need;
+    out->leaf_count = (uint32_t)(leaf_boxes.size() / 2) - out->leaf_begin;
     return RT_OK;
 }
 
@@ -425,11 +432,11 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device_id, RtScene**
         }
         o.material = t.material;
     }
-    std::vector<float4> nodes, nodes4, hot, cold;
+    std::vector<float4> nodes, nodes4, hot, cold, leaf_boxes;
     std::vector<MeshLayout> layouts(desc->n_meshes);
     uint32_t stack_entries = 1, stack_entries4 = 1;
     for (uint32_t mi = 0; mi < desc->n_meshes; ++mi) {
-        int rc = layout_mesh(desc, mi, nodes, hot, cold, &layouts[mi]);
+        int rc = layout_mesh(desc, mi, nodes, hot, cold, leaf_boxes, &layouts[mi]);
         if (rc == RT_OK) rc = collapse_mesh(nodes, mi, &layouts[mi], nodes4);
         if (rc != RT_OK) return rc;
     }
@@ -465,6 +472,17 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device_id, RtScene**
         if (!(o.world_guard == o.world_guard) || o.world_guard > 1e30f) o.prunable = 0;
         instance_world_box(in, ml, std::sqrt(fro), &o);
         if (!ml.nested) { o.prunable = 0; o.cullable = 0; }        // see MeshLayout::nested: every ray takes the exact set-up, walks are not pruned
+        // Far-away rays (DInstance::heavy_origin): the slab test's products carry an error of about 2^-22 of the origin's
+        // coordinate, so from 2^19 root-box extents out a ray looks an eighth of the mesh thick on that axis; only worth a
+        // block of its own for meshes with many leaves, and only exact for trees that nest
+        o.leaf_begin = ml.leaf_begin;
+        o.leaf_count = ml.leaf_count;
+        o.heavy_origin = INFINITY;
+        if (ml.nested && o.prunable && ml.leaf_count >= 1024) {
+            float ext = 0.0f;
+            for (int c = 0; c < 3; ++c) ext = std::max(ext, ml.root_hi[c] - ml.root_lo[c]);
+            if (ext > 0.0f && ext < 1e15f) o.heavy_origin = ext * 524288.0f;
+        }
         if (ml.stack_need > stack_entries) stack_entries = ml.stack_need;
         if (ml.stack_need4 > stack_entries4) stack_entries4 = ml.stack_need4;
     }
@@ -535,6 +553,8 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device_id, RtScene**
     }
     s->d.n_range_nodes = (uint32_t)range_limits.size();
     s->d.n_tri_slots = (uint32_t)(hot.size() / 3);
+    s->d.n_leaf_boxes = (uint32_t)(leaf_boxes.size() / 2);
+    if (const char* env = getenv("RT_HEAVY_PAIRS")) if (!atoi(env)) for (DInstance& di : instances) di.heavy_origin = INFINITY;
     s->d.range_depth = range_depth;
     s->d.all_cullable = 1;
     for (const DInstance& di : instances) {
@@ -545,7 +565,8 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device_id, RtScene**
         (rc = upload(s, planes, &s->d.planes)) || (rc = upload(s, spheres, &s->d.spheres)) ||
         (rc = upload(s, triangles, &s->d.triangles)) || (rc = upload(s, instances, &s->d.instances)) ||
         (rc = upload(s, range_nodes, &s->d.range_nodes)) || (rc = upload(s, range_limits, &s->d.range_limits)) ||
-        (rc = upload(s, nodes, &s->d.nodes)) || (rc = upload(s, nodes4, &s->d.nodes4)) || (rc = upload(s, hot, &s->d.tri_hot)) || (rc = upload(s, cold, &s->d.tri_cold)))
+        (rc = upload(s, nodes, &s->d.nodes)) || (rc = upload(s, nodes4, &s->d.nodes4)) || (rc = upload(s, hot, &s->d.tri_hot)) || (rc = upload(s, cold, &s->d.tri_cold)) ||
+        (rc = upload(s, leaf_boxes, &s->d.leaf_boxes)))
         return bail(rc);
     // five blocks per compute unit for the list kernels (measured on the 1080p bunnies frame: 4: 3.02 ms, 5: 2.93 ms,
     // 6: 2.94 ms with rt_shade squeezed into 80 registers, 8: 3.6 ms)
@@ -566,8 +587,9 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device_id, RtScene**
     // Scenes whose walk data (4-wide nodes + triangles) is far beyond the eight 4 MB L2s: neighbouring pairs walk the same
     // meshes, so the BVH walk hands them out in runs (2.6 M-triangle grid: 7.5 -> 6.2 ms per frame); cache-resident scenes
     // keep the interleaving that balances the waves (contiguous runs there: 1.24 -> 1.40 ms)
-    s->walk_contiguous = (nodes4.size() + hot.size()) * sizeof(float4) > (64u << 20);
-    if (const char* env = getenv("RT_WALK_CONTIGUOUS")) s->walk_contiguous = atoi(env) != 0;
+    // (0: never, 1: always, 2: launch by launch, where a wave gets several chunks - see rt_traverse)
+    s->walk_contiguous = (nodes4.size() + hot.size()) * sizeof(float4) > (64u << 20) ? 1u : 2u;
+    if (const char* env = getenv("RT_WALK_CONTIGUOUS")) { const int v = atoi(env); if (v >= 0 && v <= 2) s->walk_contiguous = (uint32_t)v; }
     s->h_overflow[0] = 0;
     s->h_overflow[1] = 0;
     // In a scene whose instances all have culling boxes only stray rays (non-finite or huge components) need the exact
@@ -670,7 +692,7 @@ static int carve_frame(uint32_t n_pixels, uint32_t n_lights, uint32_t blocks, ui
     sz->stats_words = (size_t)std::max<uint32_t>(blocks * 4, spill_lanes / 64) * 8;      // a row per wave of the largest grid
     // colour sums and poison words in one allocation, all counters in another: two clears per frame
     sz->pixel_clear_bytes = (size_t)3 * n_pixels * sizeof(long long) + (size_t)n_pixels * sizeof(unsigned int);
-    sz->counter_words = 2 * (RT_MAX_DEPTH_LIMIT + 2) + sz->stats_words + (size_t)RT_COUNT_ROWS * (RT_MAX_DEPTH_LIMIT + 3) * f.n_seg;
+    sz->counter_words = 3 * (RT_MAX_DEPTH_LIMIT + 2) + sz->stats_words + (size_t)RT_COUNT_ROWS * (RT_MAX_DEPTH_LIMIT + 3) * f.n_seg;
     unsigned int* counters = nullptr;
     int rc;
     auto get = [&](size_t count, auto** p) {
@@ -685,7 +707,8 @@ static int carve_frame(uint32_t n_pixels, uint32_t n_lights, uint32_t blocks, ui
         (rc = get(all_ray_slots, &f.best[0])) || (rc = get(all_ray_slots, &f.best[1])) ||
         (rc = get(fat_slots, &f.item_results[0])) || (rc = get(fat_slots, &f.item_results[1])) ||
         (rc = get(4 * fat_slots, &f.fat_items[0])) || (rc = get(4 * fat_slots, &f.fat_items[1])) || (rc = get(ray_slots, &f.slow_rays)) ||
-        (rc = get(3 * hit_slots, &f.hits[0])) || (rc = get(3 * hit_slots, &f.hits[1])))
+        (rc = get(3 * hit_slots, &f.hits[0])) || (rc = get(3 * hit_slots, &f.hits[1])) ||
+        (rc = get((size_t)(RT_MAX_DEPTH_LIMIT + 2) * RT_HEAVY_CAP, &f.heavy_items)))
         return rc;
     f.shadow_base = (uint32_t)ray_slots;
     f.n_fat_slots = (uint32_t)fat_slots;
@@ -696,6 +719,7 @@ static int carve_frame(uint32_t n_pixels, uint32_t n_lights, uint32_t blocks, ui
     // the frame can reach (enqueue_frame clears no further)
     f.chunk_counter = c; c += RT_MAX_DEPTH_LIMIT + 2;
     f.slow_flags = c; c += RT_MAX_DEPTH_LIMIT + 2;
+    f.heavy_count = c; c += RT_MAX_DEPTH_LIMIT + 2;
     f.wave_stats = c; c += sz->stats_words;
     f.counts = c;
     if (aux && ((rc = get((size_t)n_pixels, &f.aux_flags)) || (rc = get((size_t)n_pixels, &f.aux_prim)) ||
@@ -877,7 +901,7 @@ static int enqueue_frame(RtScene* s, const RtRenderParams* p, bool sharded, bool
     // a depth map only looks at the primary hits
     const uint32_t last = p->mode == RT_MODE_DEPTH_MAP ? 0 : (s->d.n_lights > 0 ? max_depth : max_depth - 1);
     // every counter, the statistics and the count rows of depths 0 .. last + 1
-    const size_t clear_words = 2 * (RT_MAX_DEPTH_LIMIT + 2) + sz.stats_words + (size_t)RT_COUNT_ROWS * (last + 2) * f.n_seg;
+    const size_t clear_words = 3 * (RT_MAX_DEPTH_LIMIT + 2) + sz.stats_words + (size_t)RT_COUNT_ROWS * (last + 2) * f.n_seg;
     HIP_TRY(hipMemsetAsync(f.chunk_counter, 0, clear_words * sizeof(unsigned int), stream));
     // the scratch array keeps what the last call on this GPU left in it
     if (noalloc) HIP_TRY(hipMemsetAsync(f.acc_big, 0, (size_t)3 * g.n_pixels * sizeof(double), stream));
@@ -1036,6 +1060,7 @@ extern "C" int rt_last_ray_counts(RtScene* s, uint64_t counters[RT_N_COUNTERS]) 
     for (int k = 0; k < 5; ++k) counters[k] = sums[k];
     counters[RT_CTR_WALK_NODE_VISITS] = sums[5];
     counters[RT_CTR_WALK_TRIANGLE_TESTS] = sums[6];
+    counters[RT_CTR_WALK_HEAVY_PAIRS] = sums[7];
     return RT_OK;
 }
 

@@ -64,6 +64,12 @@ struct DInstance {
     uint32_t cullable;              // 0: the box is not trusted (degenerate or inconsistent matrices)
     float cull_origin_limit;        // the box is only used for rays whose origin has a smaller L1 norm
     float world_lo[3], world_hi[3];
+    // A ray that starts this far out (mesh-local units) on an axis resolves none of the mesh's boxes on that axis any more -
+    // the slab test's products there all round to the same few values; with two such axes it would walk a good part of the
+    // tree, and the pair is tested against every leaf by a whole block instead (traverse_heavy_pairs).  +inf where that is
+    // not available.
+    float heavy_origin;
+    uint32_t leaf_begin, leaf_count;   // the mesh's leaves in DScene::leaf_boxes
 };
 
 // A BVH work item as the walk consumes it (64 B): the mesh-local ray and everything else it needs, so
@@ -74,7 +80,9 @@ struct DInstance {
 // shadow threshold: a candidate with local t * q2.x below it proves a shadow ray blocked (-inf for other rays).
 #define RT_FAT_FAST 0x80000000u          // the walk may prune by distance and share subtrees (DInstance::prunable)
 #define RT_FAT_DONE 0x40000000u          // no walk: the pair's result is already in item_results (ray traced on the exact path)
-#define RT_FAT_INSTANCE 0x3FFFFFFFu
+#define RT_FAT_HEAVY 0x20000000u         // not walked lane by lane: the pair is on the depth's list for traverse_heavy_pairs
+#define RT_FAT_INSTANCE 0x1FFFFFFFu
+#define RT_HEAVY_CAP 1024u               // pairs per depth traverse_heavy_pairs takes; further ones are walked as usual
 #define RT_MAX_INSTANCES (1u << 20)      // mesh instances of a scene (rt_setup packs the index into 20 bits)
 
 // A child reference: inner node index, or a leaf given by its first triangle slot and its count.
@@ -122,6 +130,12 @@ struct DScene {
     const float4* tri_hot;
     // slot s: tri_cold[3*s] = (n0.xyz, bits mesh_triangle_index), [3*s+1] = (n1.xyz, bits material), [3*s+2] = (n2.xyz, 0)
     const float4* tri_cold;
+    // The leaves of every mesh whose tree nests, mesh after mesh (DInstance::leaf_begin): leaf k is leaf_boxes[2*k] =
+    // (box min, box max.x), leaf_boxes[2*k+1] = (box max.yz, bits of the leaf's reference, 0).  In a tree whose boxes nest
+    // a ray passes a leaf's box only if it passes the boxes of all the nodes above it (the slab test is monotone in the
+    // box), so "the leaves whose own box the ray passes" are exactly the leaves the reference's walk tests.
+    uint32_t n_leaf_boxes;
+    const float4* leaf_boxes;
 };
 
 // The cameras of the views of a frame (rt_generate's own argument): column-major screen_to_world matrices.
@@ -182,11 +196,13 @@ struct DFrame {
     unsigned int* slow_flags;        // [RT_MAX_DEPTH_LIMIT + 2] set when a depth has such rays
     uint2* spill;                    // traversal stack entries beyond DScene::stack_lds: entry e of walking lane g at [e * spill_lanes + g]
     uint32_t spill_lanes;            // lanes of the BVH walk's grid
-    uint32_t walk_contiguous;        // the walk hands out runs of neighbouring pairs instead of interleaving them
+    uint32_t walk_contiguous;        // the walk hands out runs of neighbouring pairs instead of interleaving them: 0 never, 1 always, 2 in launches with several chunks per wave
     uint32_t fuse_setup;             // rt_shade sets up the rays it makes (rt_setup only runs at depth 0)
     unsigned int* chunk_counter;     // [RT_MAX_DEPTH_LIMIT + 2] input chunks of the BVH walk handed out so far, per depth
+    unsigned int* heavy_count;       // [RT_MAX_DEPTH_LIMIT + 2] pairs on the depth's list for traverse_heavy_pairs (may exceed RT_HEAVY_CAP: the rest are walked)
+    unsigned int* heavy_items;       // [RT_MAX_DEPTH_LIMIT + 2][RT_HEAVY_CAP] their walk items
     float4* hits[2];                 // Phong-shaded hits waiting for their shadow rays, 3 float4 each
-    unsigned int* wave_stats;        // [waves][8]: rays, primary, shadow, reflected, transmitted (rt_shade); 4-wide nodes visited, triangles tested (rt_traverse)
+    unsigned int* wave_stats;        // [waves][8]: rays, primary, shadow, reflected, transmitted (rt_shade); 4-wide nodes visited, triangles tested (rt_traverse); pairs taken (traverse_heavy_pairs)
     // A list did not fit (the frame is then invalid): the kernels store the frame's sequence number here.  The host
     // only ever reads the word, so no report can be lost to a clear; frames of one handle run one after the other,
     // so the word names the latest frame that overflowed.

@@ -223,6 +223,9 @@ __device__ __forceinline__ bool slab(float lx, float ly, float lz, float hx, flo
 #ifndef RT_LEAF_SHARE
 #define RT_LEAF_SHARE 2
 #endif
+#ifndef RT_CONTIGUOUS_MIN_CHUNKS
+#define RT_CONTIGUOUS_MIN_CHUNKS 4   // chunks of 64 pairs per wave from which a launch of the BVH walk hands out runs of neighbouring pairs
+#endif
 
 // Full hitpoint of the winner.
 __device__ __forceinline__ Hitpoint finalize_hit(const DScene& S, const Ray& r, const Closest& c) {
@@ -489,8 +492,9 @@ __device__ __forceinline__ uint32_t locate(const uint32_t* pre, uint32_t n_seg, 
 // must be called by all lanes of the wave; elements at or beyond `total` get an unspecified slot).  The
 // wave finds the segment of v0 in two cooperative steps - 64 samples of the table, then the bracket between
 // two samples - instead of ten dependent ones, and each lane walks on from there.
-__device__ __forceinline__ uint32_t locate_chunk(const uint32_t* pre, uint32_t n_seg, uint32_t seg_cap, uint32_t v0, uint32_t total,
-                                                 uint32_t lane) {
+// `off`: which of the consecutive elements v0, v0 + 1, ... this lane wants (lanes with !wanted get an unspecified slot).
+__device__ __forceinline__ uint32_t locate_run(const uint32_t* pre, uint32_t n_seg, uint32_t seg_cap, uint32_t v0, uint32_t off, bool wanted,
+                                               uint32_t lane) {
     uint32_t lo = 0, span = n_seg + 1;                     // the answer for v0 lies in [lo, lo + span)
     while (span > 1) {
         const uint32_t stride = (span + RT_WAVE - 1) / RT_WAVE;
@@ -501,8 +505,8 @@ __device__ __forceinline__ uint32_t locate_chunk(const uint32_t* pre, uint32_t n
         span = (lo + stride <= n_seg + 1) ? stride : n_seg + 1 - lo;
     }
     uint32_t seg = lo < n_seg ? lo : n_seg - 1;
-    const uint32_t v = v0 + lane;
-    if (v < total) {
+    const uint32_t v = v0 + off;
+    if (wanted) {
         // pre[n_seg] = total > v ends the walk; a long run of empty segments is crossed by bisection
         uint32_t steps = 0;
         while (pre[seg + 1] <= v) {
@@ -516,6 +520,10 @@ __device__ __forceinline__ uint32_t locate_chunk(const uint32_t* pre, uint32_t n
         }
     }
     return seg * seg_cap + (v - pre[seg]);
+}
+__device__ __forceinline__ uint32_t locate_chunk(const uint32_t* pre, uint32_t n_seg, uint32_t seg_cap, uint32_t v0, uint32_t total,
+                                                 uint32_t lane) {
+    return locate_run(pre, n_seg, seg_cap, v0, lane, v0 + lane < total, lane);
 }
 
 // A slot of this block's output segment for every lane that wants one (RT_REF_NONE otherwise, or when
@@ -549,6 +557,8 @@ struct LevelLists {
     unsigned long long* best;
     float4* fat_items;
     float4* item_results;
+    unsigned int* heavy_count;       // pairs left to traverse_heavy_pairs at this depth
+    unsigned int* heavy_items;
 };
 __device__ __forceinline__ LevelLists level_lists(const DFrame& F, uint32_t level) {
     LevelLists L;
@@ -562,6 +572,8 @@ __device__ __forceinline__ LevelLists level_lists(const DFrame& F, uint32_t leve
     L.best = F.best[level & 1];
     L.fat_items = F.fat_items[level & 1];
     L.item_results = F.item_results[level & 1];
+    L.heavy_count = F.heavy_count + level;
+    L.heavy_items = F.heavy_items + (size_t)level * RT_HEAVY_CAP;
     return L;
 }
 
@@ -654,11 +666,25 @@ __device__ __forceinline__ bool walk_item(const DInstance& inst, uint32_t ii, ui
     q0 = make_float4(lr.o.x, lr.o.y, lr.o.z, root_tmin);
     q1 = make_float4(lr.d.x, lr.d.y, lr.d.z, limit);
     q2 = make_float4(1.0f / dn, thr, inst.prune_abs, __uint_as_float(inst.root_ref4));
-    q3 = make_float4(__uint_as_float(gi), __uint_as_float(ii | (fast ? RT_FAT_FAST : 0u)), 0.0f, 0.0f);
+    // A ray whose local origin lies beyond heavy_origin on two axes or more has lost the boxes on those axes - its slab
+    // products there are all the same few values - and passes a tube's worth of leaves: a candidate for
+    // traverse_heavy_pairs, see store_walk_item.  (With one such axis the other two still cut the tree down.)
+    const uint32_t far_axes = (fabsf(lr.o.x) > inst.heavy_origin ? 1u : 0u) + (fabsf(lr.o.y) > inst.heavy_origin ? 1u : 0u) +
+                              (fabsf(lr.o.z) > inst.heavy_origin ? 1u : 0u);
+    const bool heavy = pass && far_axes >= 2u;
+    q3 = make_float4(__uint_as_float(gi), __uint_as_float(ii | (fast ? RT_FAT_FAST : 0u) | (heavy ? RT_FAT_HEAVY : 0u)), 0.0f, 0.0f);
     return pass;
 }
 
-__device__ __forceinline__ void store_walk_item(float4* fat_items, uint32_t slot, float4 q0, float4 q1, float4 q2, float4 q3) {
+// Stores a walk item.  One that walk_item marked heavy goes on the depth's list for traverse_heavy_pairs as well - while that
+// list has room; otherwise it loses the mark and is walked like any other (the mark only chooses who computes the pair).
+__device__ __forceinline__ void store_walk_item(const LevelLists& L, uint32_t slot, float4 q0, float4 q1, float4 q2, float4 q3) {
+    if (__float_as_uint(q3.y) & RT_FAT_HEAVY) {
+        const uint32_t k = atomicAdd(L.heavy_count, 1u);
+        if (k < RT_HEAVY_CAP) L.heavy_items[k] = slot;
+        else q3.y = __uint_as_float(__float_as_uint(q3.y) & ~RT_FAT_HEAVY);
+    }
+    float4* fat_items = L.fat_items;
     fat_items[4 * (size_t)slot] = q0; fat_items[4 * (size_t)slot + 1] = q1;
     fat_items[4 * (size_t)slot + 2] = q2; fat_items[4 * (size_t)slot + 3] = q3;
 }
@@ -716,7 +742,7 @@ __device__ __forceinline__ void ring_drain(PairRing& R, const DScene& S, const D
     R.head = (R.head + n) & (RT_RING_CAP - 1);
     R.count -= n;
     const uint32_t slot = append_slot(pass, out_n, F.seg_fat, F.n_seg, L.fat_counts, F.ovf_fat, F.overflow, F.overflow_seq, lane);
-    if (slot != RT_REF_NONE) store_walk_item(L.fat_items, slot, q0, q1, q2, q3);
+    if (slot != RT_REF_NONE) store_walk_item(L, slot, q0, q1, q2, q3);
 }
 
 // Scene::intersect's three analytic groups (scene.rs:129-131 over intersect.rs:20-36): per group the closest
@@ -809,10 +835,24 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_generate(const DFrame F, 
 // count of rounds in which some lane tested a leaf, cycles and count of the other rounds, sum of walking lanes.
 __device__ unsigned long long g_wave_timing[8192 * 10];
 __device__ unsigned long long g_shade_timing[8192 * 8];
+// per wave of the last launch that set rays up (rt_setup, or rt_shade with setup_next): cycles spent fetching the rays of its
+// chunks, on the analytic primitives, on the culling boxes, pushing and draining pairs; chunks; drains
+__device__ unsigned long long g_setup_timing[8192 * 8];
+extern "C" hipError_t rt_debug_setup_timing(unsigned long long* out, size_t n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_setup_timing), n * sizeof(unsigned long long));
+}
 extern "C" hipError_t rt_debug_shade_timing(unsigned long long* out, size_t n) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_shade_timing), n * sizeof(unsigned long long));
 }
 __device__ unsigned int g_walk_items[64];
+// walks of more than 300 node visits by one walker: {level, item, ray slot, instance, visits, 0, 0, 0, the item's 16 words}
+#ifndef RT_DEBUG_LONG_LEVEL
+#define RT_DEBUG_LONG_LEVEL 4
+#endif
+__device__ unsigned int g_long_walks[1 + 64 * 24];
+extern "C" hipError_t rt_debug_long_walks(unsigned int* out, size_t n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_long_walks), n * sizeof(unsigned int));
+}
 extern "C" hipError_t rt_debug_walk_items(unsigned int* out, size_t n) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_walk_items), n * sizeof(unsigned int));
 }
@@ -898,7 +938,17 @@ __device__ __forceinline__ void setup_rays(const DScene& S, const DFrame& F, con
     // never mixes the two kinds, nor two lights).
     const uint32_t main_chunks = (in.n_rays + RT_WAVE - 1) / RT_WAVE, hit_chunks = (in.n_hits + RT_WAVE - 1) / RT_WAVE;
     const uint32_t all_chunks = main_chunks + S.n_lights * hit_chunks;
+#ifdef RT_STATS
+    unsigned long long su[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define RT_SU_MARK(k) { const unsigned long long now_ = clock64(); su[k] += now_ - su_t; su_t = now_; }
+#else
+#define RT_SU_MARK(k)
+#endif
     for (uint32_t c = my_wave; c < all_chunks; c += n_waves) {
+#ifdef RT_STATS
+        unsigned long long su_t = clock64();
+        su[4] += 1;
+#endif
         bool active;
         uint32_t gi = 0;
         RayRec rr;
@@ -943,10 +993,12 @@ __device__ __forceinline__ void setup_rays(const DScene& S, const DFrame& F, con
         // planes, spheres, triangles: intersect.rs:20-36 per kind, merged as scene.rs:129-131
         bool have = false; float best_t = 0.0f; uint32_t best_order = 0;
         bool settled = false;
+        RT_SU_MARK(0)
         if (active) {
             if (staged) analytic_hits(S, ld_planes, ld_spheres, ld_triangles, r, early, ss, have, best_t, best_order, settled);
             else analytic_hits(S, S.planes, S.spheres, S.triangles, r, early, ss, have, best_t, best_order, settled);
         }
+        RT_SU_MARK(1)
         // mesh instances in Vec order (scene.rs:133-136): a world-space culling box decides whether the ray can touch the
         // instance at all within the distance that still matters; the pairs that remain wait in the wave's ring for their
         // local ray and the reference's root-box test (ring_drain)
@@ -1001,6 +1053,7 @@ __device__ __forceinline__ void setup_rays(const DScene& S, const DFrame& F, con
                 want_bits |= (w ? 1u : 0u) << ii;
             }
         }
+        RT_SU_MARK(2)
         for (uint32_t ii = 0; ii < (S.n_range_nodes ? 0u : S.n_instances); ++ii) {
             if (cull_words) {
                 const bool want_item = (want_bits >> ii) & 1u;
@@ -1023,7 +1076,14 @@ __device__ __forceinline__ void setup_rays(const DScene& S, const DFrame& F, con
             if (R.count >= RT_WAVE) ring_drain(R, S, F, L, &out_n, lane);
         }
         if (active) L.best[gi] = have ? make_key(best_t, best_order) : RT_KEY_NONE;
+        RT_SU_MARK(3)
     }
+#ifdef RT_STATS
+    {
+        const uint32_t gw = (blockIdx.x * blockDim.x + threadIdx.x) / RT_WAVE;
+        if (lane == 0 && gw < 8192) for (int k = 0; k < 8; ++k) g_setup_timing[gw * 8 + k] = su[k];
+    }
+#endif
     while (R.count) ring_drain(R, S, F, L, &out_n, lane);           // the pairs still waiting
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1156,14 +1216,14 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_setup_slow(const DScene S
             float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
             if (want_item) want_item = walk_item(inst, ii, gi, r, ss, lw, q0, q1, q2, q3);
             const uint32_t slot = append_slot(want_item, &out_n, F.seg_fat, F.n_seg, L.fat_counts, F.ovf_fat, F.overflow, F.overflow_seq, lane);
-            if (slot != RT_REF_NONE) store_walk_item(L.fat_items, slot, q0, q1, q2, q3);
+            if (slot != RT_REF_NONE) store_walk_item(L, slot, q0, q1, q2, q3);
         }
         // a mesh winner found on the exact path is recorded as a finished work item
         {
             uint32_t slot = append_slot(active && exact_mesh, &out_n, F.seg_fat, F.n_seg, L.fat_counts, F.ovf_fat, F.overflow, F.overflow_seq, lane);
             if (slot != RT_REF_NONE) {
                 const float4 z = make_float4(0, 0, 0, 0);
-                store_walk_item(L.fat_items, slot, z, z, z, make_float4(__uint_as_float(gi), __uint_as_float(ex_inst | RT_FAT_DONE), 0.0f, 0.0f));
+                store_walk_item(L, slot, z, z, z, make_float4(__uint_as_float(gi), __uint_as_float(ex_inst | RT_FAT_DONE), 0.0f, 0.0f));
                 L.item_results[slot] = make_float4(ex_t, ex_u, ex_v, __uint_as_float(ex_slot));
                 best_order = RT_KEY_MESH | slot;
             } else if (active && exact_mesh) {
@@ -1182,6 +1242,93 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_setup_slow(const DScene S
     __syncthreads();
     if (threadIdx.x == 0) L.fat_counts[blockIdx.x] = out_n < F.seg_fat ? out_n : F.seg_fat;
 }
+
+// ======================================================================================================
+// First part of kernel B, done by its first blocks: the pairs walk_item left on the depth's heavy list - rays that enter a
+// mesh's root box so far out that the slab test (intersect.rs:185-226) no longer tells the mesh's boxes apart: nearly
+// every box "passes", the reference tests nearly every triangle (82 000 of them for one shadow ray of the 1080p bunnies
+// frame, seen from a hit point 5e8 units down the mirror floor), and a lane-by-lane walk of such a pair keeps one wave
+// busy for milliseconds while the launch waits.  The list is complete before the launch starts (rt_setup or rt_shade
+// wrote it), so the blocks that take it need nobody else's work; the other blocks meanwhile start on the walk items,
+// which are handed out chunk by chunk.  A block takes one pair at a time and its lanes take the mesh's leaves side by
+// side: a leaf counts when the ray passes the leaf's own box - in a tree whose boxes nest that is the case exactly when
+// it passes every box above it as well - and its triangles are tested as in the walk; the closest candidate by (t, slot)
+// is what any visiting order yields.
+// ======================================================================================================
+#define RT_HEAVY_BLOCKS 32
+// Block-wide: every thread of the first `heavy_blocks` blocks of rt_traverse calls it.
+__device__ void traverse_heavy_pairs(const DScene& S, const DFrame& F, const uint32_t level, const uint32_t heavy_blocks) {
+    const LevelLists L = level_lists(F, level);
+    const uint32_t n = *L.heavy_count < RT_HEAVY_CAP ? *L.heavy_count : RT_HEAVY_CAP;
+    __shared__ unsigned long long best_key;
+    uint32_t n_boxes = 0, n_triangle_tests = 0;
+    for (uint32_t e = blockIdx.x; e < n; e += heavy_blocks) {
+        if (threadIdx.x == 0) best_key = RT_KEY_NONE;
+        __syncthreads();
+        const uint32_t item = L.heavy_items[e];
+        const float4 q0 = L.fat_items[4 * (size_t)item], q1 = L.fat_items[4 * (size_t)item + 1], q3 = L.fat_items[4 * (size_t)item + 3];
+        Ray lr;
+        lr.o = mk(q0.x, q0.y, q0.z);
+        lr.d = mk(q1.x, q1.y, q1.z);
+        const V3 inv = mk(1.0f / lr.d.x, 1.0f / lr.d.y, 1.0f / lr.d.z);
+        const uint32_t gi = __float_as_uint(q3.x), ii = __float_as_uint(q3.y) & RT_FAT_INSTANCE;
+        const DInstance& inst = S.instances[ii];
+        bool m_have = false; float m_t = 0.0f; uint32_t m_slot = 0;
+        // (the next leaf's box is requested before this leaf's triangles, and a leaf's triangles all together: two round
+        // trips to memory per leaf instead of six)
+        const float4* boxes = S.leaf_boxes + 2 * (size_t)inst.leaf_begin;
+        uint32_t k = threadIdx.x;
+        float4 b0 = make_float4(0, 0, 0, 0), b1 = b0;
+        if (k < inst.leaf_count) { b0 = boxes[2 * (size_t)k]; b1 = boxes[2 * (size_t)k + 1]; }
+        while (k < inst.leaf_count) {
+            const float4 c0 = b0, c1 = b1;
+            k += blockDim.x;
+            if (k < inst.leaf_count) { b0 = boxes[2 * (size_t)k]; b1 = boxes[2 * (size_t)k + 1]; }
+            float tmin;
+            ++n_boxes;
+            if (!slab(c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, lr.o, inv, tmin)) continue;
+            const uint32_t ref = __float_as_uint(c1.z), first = ref & RT_REF_SLOT_MASK, cnt = (ref >> RT_REF_COUNT_SHIFT) & 7u;
+            n_triangle_tests += cnt;
+            float4 h[RT_LEAF_TRIANGLES][3];
+#pragma unroll
+            for (uint32_t j = 0; j < RT_LEAF_TRIANGLES; ++j) {
+                const uint32_t slot = first + (j < cnt ? j : cnt - 1);          // (entries past the leaf's count repeat its last triangle)
+                h[j][0] = S.tri_hot[3 * slot]; h[j][1] = S.tri_hot[3 * slot + 1]; h[j][2] = S.tri_hot[3 * slot + 2];
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < RT_LEAF_TRIANGLES; ++j) {
+                const uint32_t slot = first + j;
+                float t, u, v;
+                if (j < cnt && triangle_tuv(mk(h[j][0].x, h[j][0].y, h[j][0].z), mk(h[j][0].w, h[j][1].x, h[j][1].y), mk(h[j][1].z, h[j][1].w, h[j][2].x), lr, t, u, v) &&
+                    (!m_have || t < m_t || (t == m_t && slot < m_slot))) {
+                    m_have = true; m_t = t; m_slot = slot;
+                }
+            }
+        }
+        if (m_have) atomicMin(&best_key, make_key(m_t, m_slot));
+        __syncthreads();
+        if (threadIdx.x == 0 && best_key != RT_KEY_NONE) {
+            // the pair's closest hit joins the ray's other candidates as in rt_traverse (scene.rs:133-136)
+            const uint32_t win_slot = (uint32_t)best_key;
+            const float4 h0 = S.tri_hot[3 * win_slot], h1 = S.tri_hot[3 * win_slot + 1], h2 = S.tri_hot[3 * win_slot + 2];
+            float t = 0.0f, u = 0.0f, v = 0.0f;
+            triangle_tuv(mk(h0.x, h0.y, h0.z), mk(h0.w, h1.x, h1.y), mk(h1.z, h1.w, h2.x), lr, t, u, v);
+            const float tw = world_t(S, inst, lr, load_any_origin(S, F, level, gi), t, win_slot);
+            L.item_results[item] = make_float4(t, u, v, __uint_as_float(win_slot));
+            atomicMin(&L.best[gi], make_key(tw, RT_KEY_MESH | item));
+        }
+        __syncthreads();
+    }
+    // work statistics, in the rows of the walk's counters (four boxes count as one node visit)
+    if (n) {
+        const uint32_t lane = threadIdx.x & (RT_WAVE - 1), gwave = (blockIdx.x * blockDim.x + threadIdx.x) / RT_WAVE;
+        uint32_t a = n_boxes, b = n_triangle_tests;
+        for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
+        if (lane == 0 && (a | b)) { F.wave_stats[(size_t)gwave * 8 + 5] += (a + 3) / 4; F.wave_stats[(size_t)gwave * 8 + 6] += b; }
+        if (threadIdx.x == 0 && blockIdx.x < n) F.wave_stats[(size_t)gwave * 8 + 7] += (n - blockIdx.x + heavy_blocks - 1) / heavy_blocks;      // the pairs this block took
+    }
+}
+
 
 // ======================================================================================================
 // Kernel B: BVH traversal of the work items, one (ray, instance) pair per lane, lanes refilled as they
@@ -1207,6 +1354,10 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
     const unsigned long long t_begin = clock64(), w_begin = wall_clock64();
 #endif
     const LevelLists L = level_lists(F, level);
+    {
+        const uint32_t heavy_blocks = gridDim.x < RT_HEAVY_BLOCKS ? gridDim.x : RT_HEAVY_BLOCKS;
+        if (blockIdx.x < heavy_blocks && *L.heavy_count != 0) traverse_heavy_pairs(S, F, level, heavy_blocks);
+    }
     extern __shared__ uint32_t lds[];
     uint32_t* pre = lds;
     uint32_t* scratch = lds + F.n_seg + 1;
@@ -1233,7 +1384,12 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
     // With less than 64 pairs per wave the chunks shrink, so that every wave gets some and shares the long ones.
     const bool one_chunk_each = (unsigned long long)n_waves * RT_WAVE >= n_items;
     const uint32_t n_chunks = one_chunk_each ? n_waves : (n_items + RT_WAVE - 1) / RT_WAVE;
-    const bool contiguous = F.walk_contiguous != 0;
+    // neighbouring pairs walk the same parts of the same meshes.  Interleaved over the waves they even out what a wave has to
+    // do, which is what a launch with a chunk or two per wave needs; handed out in runs they keep a wave's fetches in few
+    // cache lines, which pays once a wave gets several chunks of a launch (F.walk_contiguous == 2), or always in scenes far
+    // larger than the caches (1)
+    const bool contiguous = F.walk_contiguous == 1 ||
+                            (F.walk_contiguous == 2 && n_items >= (unsigned long long)RT_CONTIGUOUS_MIN_CHUNKS * n_waves * RT_WAVE);
     const uint32_t chunk_len = (n_items + n_chunks - 1) / n_chunks;
     uint32_t my_chunk = gwave, cur_chunk = 0, chunk_next = 0, chunk_end = 0;       // wave-uniform
     bool exhausted = false;
@@ -1256,7 +1412,7 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
     bool m_have = false; float m_t = 0.0f, m_u = 0.0f, m_v = 0.0f; uint32_t m_slot = 0;
     uint32_t n_node_visits = 0, n_triangle_tests = 0;      // this lane's share of the launch's work, for the statistics
 #ifdef RT_STATS
-    uint32_t dbg_steps = 0;
+    uint32_t dbg_steps = 0, dbg_walk_steps = 0;
     unsigned long long tm[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     tm[2] = clock64() - t_begin;           // building the prefix table
     if (threadIdx.x == 0 && blockIdx.x == 0 && level < 64) g_walk_items[level] = n_items;
@@ -1342,17 +1498,22 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
             const uint32_t avail = chunk_end - chunk_next;
             if (avail == 0 && run_mask == 0) break;                 // exhausted and nothing in flight
             const uint32_t asking = __popcll(idle_mask);
+            const uint32_t rank = __popcll(idle_mask & ((1ull << lane) - 1ull));
+            const bool takes = !running && rank < avail;
+            // a run of neighbouring pairs lies in one list segment or a few: the wave finds the first one's together
+            uint32_t run_slot = 0;
+            if (contiguous && avail != 0 && asking != 0)
+                run_slot = locate_run(pre, F.n_seg, F.seg_fat, cur_chunk * chunk_len + chunk_next, rank, takes, lane);
             if (!running) {
-                const uint32_t rank = __popcll(idle_mask & ((1ull << lane) - 1ull));
                 if (rank < avail) {
                     // Element j of chunk c is pair c + j * n_chunks: neighbouring pairs (similar rays, similar cost) go to
                     // different chunks.  A 64-byte item is a cache line of its own either way.
-                    const size_t fat = locate(pre, F.n_seg, F.seg_fat, contiguous ? cur_chunk * chunk_len + chunk_next + rank
-                                                                                : cur_chunk + (chunk_next + rank) * n_chunks);
+                    const size_t fat = contiguous ? run_slot : locate(pre, F.n_seg, F.seg_fat, cur_chunk + (chunk_next + rank) * n_chunks);
                     const float4 q0 = L.fat_items[4 * fat], q1 = L.fat_items[4 * fat + 1], q2 = L.fat_items[4 * fat + 2],
                                  q3 = L.fat_items[4 * fat + 3];
                     // (an entry of a ray traced on the exact path only records a result, see rt_setup_slow: there is nothing to walk)
-                    if (!(__float_as_uint(q3.y) & RT_FAT_DONE)) {
+                    // (nor in an entry left to traverse_heavy_pairs)
+                    if (!(__float_as_uint(q3.y) & (RT_FAT_DONE | RT_FAT_HEAVY))) {
                     lr.o = mk(q0.x, q0.y, q0.z);
                     lr.d = mk(q1.x, q1.y, q1.z);
                     inv = mk(1.0f / lr.d.x, 1.0f / lr.d.y, 1.0f / lr.d.z);
@@ -1362,6 +1523,9 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
                     ii = __float_as_uint(q3.y) & RT_FAT_INSTANCE;
                     fast = (__float_as_uint(q3.y) & RT_FAT_FAST) != 0;
                     item = (uint32_t)fat;
+#ifdef RT_STATS
+                    dbg_walk_steps = 0;
+#endif
                     m_have = false; m_t = 0.0f; m_u = 0.0f; m_v = 0.0f; m_slot = 0;
                     cur_ref = __float_as_uint(q2.w);
                     cur_t = q0.w;
@@ -1497,6 +1661,17 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
                 } else {
                     // up to four entries, stored in the order the reference's walk would reach them
                     ++n_node_visits;
+#ifdef RT_STATS
+                    if (++dbg_walk_steps == 60 && level == RT_DEBUG_LONG_LEVEL) {
+                        const uint32_t k = atomicAdd(&g_long_walks[0], 1u);
+                        if (k < 64) {
+                            unsigned int* o = g_long_walks + 1 + 24 * k;
+                            o[0] = level; o[1] = item; o[2] = gi; o[3] = ii; o[4] = dbg_walk_steps;
+                            const float4* q = L.fat_items + 4 * (size_t)item;
+                            for (int j = 0; j < 4; ++j) { o[8 + 4 * j] = __float_as_uint(q[j].x); o[9 + 4 * j] = __float_as_uint(q[j].y); o[10 + 4 * j] = __float_as_uint(q[j].z); o[11 + 4 * j] = __float_as_uint(q[j].w); }
+                        }
+                    }
+#endif
                     const float4* nq = S.nodes4 + 8 * (size_t)cur_ref;
                     const float4 nd0 = nq[0], nd1 = nq[1], nd2 = nq[2], nd3 = nq[3], nd4 = nq[4], nd5 = nq[5], nd6 = nq[6];
                     float t0, t1, t2, t3;

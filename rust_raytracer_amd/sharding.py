@@ -70,7 +70,7 @@ class ShardedFrame:
     """
 
     def __init__(self, width, height, channels, rank, world_size, device, render_shard, assemble_fn, gather_fn=None,
-                 views=1):
+                 views=1, always_gather=False):
         import torch
         self.torch = torch
         self.rank, self.world = rank, world_size
@@ -78,7 +78,10 @@ class ShardedFrame:
         nbytes = shard_bytes(width, height, world_size, channels) * views      # `views` frames travel together
         self.shard = torch.zeros(nbytes, dtype=torch.uint8, device=device)
         self.frame = torch.zeros(views * height * width * channels, dtype=torch.uint8, device=device)
-        self.gathered = torch.zeros(nbytes * world_size, dtype=torch.uint8, device=device) if world_size > 1 else None
+        # always_gather: a single rank goes through the exchange step as well (its "shard" is the whole frame, the gather
+        # of one buffer a copy made by the collective library) - the way to run the collective branch on a one-GPU box
+        self.always_gather = always_gather
+        self.gathered = torch.zeros(nbytes * world_size, dtype=torch.uint8, device=device) if (world_size > 1 or always_gather) else None
         self.render_shard, self.assemble_fn = render_shard, assemble_fn
         if gather_fn is None:
             import torch.distributed as dist
@@ -86,7 +89,7 @@ class ShardedFrame:
         self.gather_fn = gather_fn
 
     def step(self):
-        if self.world == 1:
+        if self.world == 1 and not self.always_gather:
             self.render_shard(self.frame)
             return self.frame
         self.render_shard(self.shard)

@@ -389,3 +389,58 @@ def pruning_stress_scene(model_dir: str, seed: int = 0):
                parallel_camera(-0.2, sliver_y - 8.0 / 1048576.0, 1.0 / 256.0, 96, 96, 1.0 / 1048576.0),  # 2^-20 per row across the slivers
                parallel_camera(-0.99, -0.99, 0.0123, 170, 170)]                          # a generic lattice of rays
     return json.dumps(scene), cameras
+
+
+def far_origin_scene(model_dir: str, level: int = 4):
+    """Nine instances of a mesh of many leaves seen through parallel rays that start 2^21 units away on every axis: at that
+    distance the slab test of intersect.rs:185-226 tells none of the mesh's boxes apart (its products all round to a few
+    neighbouring values), so every ray is a tube a quarter of a unit thick that passes whatever leaf box comes near it, and
+    the reference tests all their triangles - the pairs the device path hands to traverse_heavy_pairs instead of walking
+    them.  The first frame holds more such pairs than that code takes per depth, so the rest are walked as usual, side by
+    side with it; the second looks nearly along -z from 10^7 units: for the instances that are not turned two of the three
+    slabs still resolve the boxes - rays that are far away but thin, and are walked - while the turned ones see the ray's
+    origin far out on two of their own axes.
+
+    Returns (scene JSON text, [(screen_to_world column-major 16 floats, width, height)] of the two cameras)."""
+    from . import meshes
+    os.makedirs(model_dir, exist_ok=True)
+    with open(os.path.join(model_dir, "ball.obj"), "w") as fh:
+        fh.write(meshes.obj_text(*meshes.jittered_icosphere(level, 0x9E3779B9)))
+    instances = []
+    for i in range(3):
+        for j in range(3):
+            inst = {"mesh": "ball", "position": _xyz(-2.5 + 2.5 * i, -2.5 + 2.5 * j, -0.4 * (i + j)),
+                    "orientation_degrees": _xyz(10 * i, 20 * j, 30), "scale": _xyz(1, 1.1 - 0.1 * i, 1)}
+            if (i + j) % 2:
+                inst["material_override"] = "mirror"
+            instances.append(inst)
+    scene = {
+        "camera": {"position": _xyz(0, 0, 4), "orientation_degrees": _xyz(0, 0, 0), "screen_dimensions": [48, 48], "y_fov_degrees": 40,
+                   "z_near": 0.1, "z_far": 60, "use_perspective": True, "ortho_world_height": 10},
+        "background": "ColoredDirection",
+        "lights": [{"position": {"x": 2.0, "y": 3.0, "z": 4.0, "w": 1},
+                    "color": {"ambient": _rgb(0.2, 0.2, 0.2), "diffuse": _rgb(0.6, 0.6, 0.6), "specular": _rgb(0.3, 0.3, 0.3)}}],
+        "materials": [{"name": "matte", "emissive": _rgb(0.02, 0.02, 0.05), "ambient": _rgb(0.3, 0.3, 0.4), "diffuse": _rgb(0.5, 0.6, 0.7),
+                       "specular": _rgb(0.4, 0.4, 0.4), "shininess": 9, "material_type": "Phong"},
+                      {"name": "mirror", "emissive": _rgb(0, 0, 0), "ambient": _rgb(0.1, 0.1, 0.1), "diffuse": _rgb(0.2, 0.2, 0.2),
+                       "specular": _rgb(0.7, 0.7, 0.7), "shininess": 30, "material_type": "ReflectAndPhong"}],
+        "planes": [{"normal": _xyz(0, 0, 1), "distance": -3.0, "material": "matte"}],
+        "spheres": [], "triangles": [],
+        "meshes": [{"name": "ball", "file_name": "ball.obj", "winding_order": "CounterClockwise", "material": "matte"}],
+        "mesh_instances": instances,
+    }
+    # pixel (x, y) -> origin (-8 + x / 4, -8 + y / 4, 0) + 2^21 * (1, 1, 1), direction along (-1, -1, -1): multiples of the
+    # spacing of float32 at 2^21 (a quarter)  (raytracer.rs:30-51 with an affine matrix)
+    far = 2.0 ** 21
+    m1 = [0.0] * 16
+    m1[0] = 0.25; m1[5] = 0.25
+    m1[8], m1[9], m1[10] = -1.0, -1.0, -1.0
+    m1[12], m1[13], m1[14], m1[15] = -8.0 + far, -8.0 + far, far, 1.0
+    # pixel (x, y) -> origin target(x, y) - 1e7 * (2^-10, 2^-9, -1), direction along (2^-10, 2^-9, -1), target(x, y) =
+    # (-4 + x / 8, -4 + y / 8, 0); powers of two, so that the difference of the two unprojected points the direction is
+    # made of survives float32 at these magnitudes
+    m2 = [0.0] * 16
+    m2[0] = 0.125; m2[5] = 0.125
+    m2[8], m2[9], m2[10] = 2.0 ** -10, 2.0 ** -9, -1.0
+    m2[12], m2[13], m2[14], m2[15] = -4.0 - 1e7 * 2.0 ** -10, -4.0 - 1e7 * 2.0 ** -9, 1e7, 1.0
+    return json.dumps(scene), [(m1, 64, 64), (m2, 64, 64)]

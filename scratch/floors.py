@@ -9,13 +9,17 @@ md = meshes.ensure_model_dir()
 host = native.HostScene.load('scenes/reflective_bunnies.json', md)
 host.resize_screen(1920, 1080)
 dev = native.DeviceScene(host.desc(), 0)
+k = int(os.environ.get('CAMERA_K', '0'))                  # drag camera k of bench.py
+if k:
+    step = 12.0 * ((k + 1) // 2)
+    host.turn_camera(0.0, 0.0, step if k % 2 else -step, 0.0)
 m, w, h = host.camera(); dev.set_camera(m, w, h)
 side = torch.cuda.Stream(); torch.cuda.set_stream(side); stream = side.cuda_stream
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 buf = torch.zeros(dev.shard_bytes(n), dtype=torch.uint8, device='cuda')
 L = native.lib()
 L.rt_debug_wave_timing.argtypes = [C.c_void_p, C.c_size_t]
-for level in range(0, 11):
+for level in [int(x) for x in os.environ.get('LEVELS', '0,1,2,3,4,5,6,7,8,9,10').split(',')]:
     os.environ['RT_DEBUG_STOP_LEVEL'] = str(level)
     for _ in range(2):
         dev.render_device(buf.data_ptr(), shard_index=0, shard_count=n, stream=stream); torch.cuda.synchronize()

@@ -1,4 +1,5 @@
 # A few frames of a bench.py workload, one at a time, for rocprofv3 passes: python3 scratch/frames.py <workload> [frames]
+# VIEWS=n: passes of n frames (n cameras 12 pixels of drag apart, as in bench.py) instead of single frames
 import sys, os
 sys.path.insert(0, '/root/repo')
 import bench
@@ -23,6 +24,23 @@ else:
 host.resize_screen(width, height)
 dev = native.DeviceScene(host.desc(), 0)
 m, w, h = host.camera(); dev.set_camera(m, w, h)
-for _ in range(n):
-    r = dev.render(max_depth=max_depth)
-print(name, int(r['counters'][0]), 'rays', dev.last_trace_ms(), 'ms')
+views = int(os.environ.get('VIEWS', '1'))
+if views > 1:
+    import numpy as np, torch
+    position0, orientation0 = host.camera_pose()
+    cams = [np.asarray(m, dtype=np.float32).reshape(16)]
+    for k in range(1, views):
+        host.set_camera_pose(position0, orientation0)
+        step = 12.0 * ((k + 1) // 2)
+        host.turn_camera(0.0, 0.0, step if k % 2 else -step, 0.0)
+        cams.append(np.asarray(host.camera()[0], dtype=np.float32).reshape(16))
+    dev.set_views(np.stack(cams), w, h)
+    buf = torch.zeros(views * w * h * 3, dtype=torch.uint8, device='cuda')
+    for _ in range(n):
+        dev.render_device(buf.data_ptr(), max_depth=max_depth)
+        c = dev.last_ray_counts()
+    print(name, int(c[0]), 'rays in a pass of', views, 'views', dev.last_trace_ms(), 'ms')
+else:
+    for _ in range(n):
+        r = dev.render(max_depth=max_depth)
+    print(name, int(r['counters'][0]), 'rays', dev.last_trace_ms(), 'ms')

@@ -19,7 +19,18 @@ for name in names:
         host = native.HostScene.load('/root/repo/scenes/' + scene_file, meshes.ensure_model_dir())
     host.resize_screen(width, height)
     dev = native.DeviceScene(host.desc(), 0)
-    m, w, h = host.camera(); dev.set_views(np.tile(np.asarray(m, dtype=np.float32).reshape(1, 16), (views, 1)), w, h)
+    m, w, h = host.camera()
+    # the views of a pass: the scene's own camera and drags of it, 12 pixels apart, as in bench.py (SAME_CAMERA=1: copies of one camera)
+    cams = [np.asarray(m, dtype=np.float32).reshape(16)]
+    position0, orientation0 = host.camera_pose()
+    for k in range(1, views):
+        if os.environ.get('SAME_CAMERA') == '1': cams.append(cams[0]); continue
+        host.set_camera_pose(position0, orientation0)
+        step = 12.0 * ((k + 1) // 2)
+        host.turn_camera(0.0, 0.0, step if k % 2 else -step, 0.0)
+        cams.append(np.asarray(host.camera()[0], dtype=np.float32).reshape(16))
+    host.set_camera_pose(position0, orientation0)
+    dev.set_views(np.stack(cams), w, h)
     buf = torch.zeros(views * w * h * 3, dtype=torch.uint8, device='cuda')
     for shards in (1, 8):
         for _ in range(3):

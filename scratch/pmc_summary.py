@@ -14,7 +14,10 @@ def per_kernel(d, counter):
 
 fetch, nf = per_kernel(sys.argv[1], 'FETCH_SIZE')
 write, nw = per_kernel(sys.argv[2], 'WRITE_SIZE')
-out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over 3 frames (one at a time) of the bench.py workload " + (sys.argv[4] if len(sys.argv) > 4 else "reflective_bunnies_1080p"),
+views = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over 3 " + ("passes of %d frames" % views if views > 1 else "frames (one at a time)") +
+                 " of the bench.py workload " + (sys.argv[4] if len(sys.argv) > 4 else "reflective_bunnies_1080p"),
+       "views": views,
        "correction": "FETCH_SIZE KiB x 1024 x 2 (gfx950 tallies 128-B requests as 64 B); WRITE_SIZE KiB x 1024", "kernels": {}}
 for k in fetch:
     fb = fetch[k] * 1024 * 2 / nf[k]

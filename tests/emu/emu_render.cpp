@@ -55,6 +55,17 @@ int main(int argc, char** argv) {
         if (rt_scene_create(desc, 0, &scene) != RT_OK) { fprintf(stderr, "%s: create: %s\n", path, rt_last_error()); rt_host_scene_destroy(host); ++failures; continue; }
         float m[16]; uint32_t w = 0, h = 0;
         rt_host_scene_camera(host, m, &w, &h);
+        {   // optional camera matrix, written next to the scene: <scene>.camera = 16 floats (column-major screen_to_world), width, height
+            FILE* f = fopen((std::string(path) + ".camera").c_str(), "r");
+            if (f) {
+                float mm[16]; unsigned ww = 0, hh = 0;
+                bool ok = true;
+                for (int k = 0; k < 16; ++k) ok = ok && fscanf(f, "%g", &mm[k]) == 1;
+                ok = ok && fscanf(f, "%u %u", &ww, &hh) == 2;
+                if (ok) { memcpy(m, mm, sizeof(m)); w = ww; h = hh; }
+                fclose(f);
+            }
+        }
         rt_scene_set_camera(scene, m, w, h);
         if (const char* cap = getenv("EMU_QUEUE_CAPACITY")) rt_debug_set_queue_capacity(scene, (uint32_t)atoi(cap));   // forces overflows, as the tests do
         const size_t n = (size_t)w * h;

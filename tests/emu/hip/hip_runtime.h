@@ -83,6 +83,20 @@ static inline unsigned int __builtin_amdgcn_readfirstlane(unsigned int v) {
     const unsigned long long* s = emu::wave_exchange(v, &live);
     return (unsigned int)s[__builtin_ctzll(live)];
 }
+// DPP operand: the lane reads `v` of another lane of its row.  The controls the kernels use: quad permutes (0x00-0xFF, two
+// bits per lane of the quad), row_mirror (0x140), row_half_mirror (0x141).
+static inline int __builtin_amdgcn_update_dpp(int old, int v, int ctrl, int, int, bool bound_ctrl) {
+    unsigned long long live;
+    const unsigned long long* s = emu::wave_exchange((unsigned int)v, &live);
+    const unsigned int l = emu::lane();
+    unsigned int src;
+    if (ctrl >= 0 && ctrl < 0x100) src = (l & ~3u) | (((unsigned int)ctrl >> (2 * (l & 3u))) & 3u);
+    else if (ctrl == 0x140) src = (l & ~15u) | (15u - (l & 15u));
+    else if (ctrl == 0x141) src = (l & ~7u) | (7u - (l & 7u));
+    else abort();
+    if ((live >> src) & 1) return (int)(unsigned int)s[src];
+    return bound_ctrl ? 0 : old;
+}
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 static inline unsigned int __float_as_uint(float f) { unsigned int u; memcpy(&u, &f, 4); return u; }

@@ -236,6 +236,31 @@ def test_pruning_bound_adversarial(tmp_path_factory, seed):
         dev.close()
 
 
+def test_rays_from_far_away(tmp_path_factory):
+    """synthetic.far_origin_scene: rays that start 2^21 units away on every axis pass whatever box of a mesh comes near them (the slab test of
+    intersect.rs:185-226 cannot tell the boxes apart at that distance), and the reference tests nearly every triangle for
+    each of them.  Such pairs go to traverse_heavy_pairs - a block tests all leaves side by side - up to a number per depth,
+    which this frame exceeds: both ways of computing a pair must give the reference's hit, t and colour."""
+    from rust_raytracer_amd import synthetic
+    d = str(tmp_path_factory.mktemp("far_models"))
+    text, cameras = synthetic.far_origin_scene(d, 5)
+    s = orc.OracleScene.from_text(text, d)
+    dev = native.DeviceScene(s.desc(), 0)
+    try:
+        heavy = []
+        for m, w, h in cameras:
+            m = np.asarray(m, dtype=np.float32)
+            s.set_camera_matrix(m, w, h)
+            dev.set_camera(m, w, h)
+            got, want = dev.render(max_depth=3, aux=True), s.render(max_depth=3)
+            assert_parity(got, want)
+            assert (got["prim_id"] >> 30 == abi.RT_PRIM_MESH_TRIANGLE).sum() > w * h // 8
+            heavy.append(int(got["counters"][abi.RT_CTR_WALK_HEAVY_PAIRS]))
+        assert heavy[0] >= 1024 and heavy[1] > 0, heavy               # the first frame has more such pairs than are taken per depth
+    finally:
+        dev.close()
+
+
 @pytest.mark.parametrize("grid,n_meshes,level,width,height", [(4, 4, 3, 480, 270), (7, 5, 2, 320, 180)])
 def test_instance_grid(tmp_path_factory, grid, n_meshes, level, width, height):
     """Many instances over several distinct meshes, arbitrary rotations and non-uniform scales, two lights,

@@ -32,10 +32,13 @@ def emu_render():
     return os.path.join(EMU, "emu_render")
 
 
-def render_and_compare(emu_render, scene_text, model_dir, work, max_depth, queue_capacity=0, shrink_bvh=False):
+def render_and_compare(emu_render, scene_text, model_dir, work, max_depth, queue_capacity=0, shrink_bvh=False, camera=None):
     path = os.path.join(work, "scene.json")
     with open(path, "w") as f:
         f.write(scene_text)
+    if camera is not None:                                            # (screen_to_world column-major, width, height) instead of the scene's own
+        with open(path + ".camera", "w") as f:
+            f.write(" ".join("%.9g" % x for x in np.asarray(camera[0], dtype=np.float32)) + " %d %d\n" % (camera[1], camera[2]))
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
     if queue_capacity:
         env["EMU_QUEUE_CAPACITY"] = str(queue_capacity)
@@ -48,6 +51,8 @@ def render_and_compare(emu_render, scene_text, model_dir, work, max_depth, queue
     try:
         if shrink_bvh:
             assert synthetic.shrink_bvh_boxes(s.desc()) > 0           # the oracle's own arrays, in place
+        if camera is not None:
+            s.set_camera_matrix(np.asarray(camera[0], dtype=np.float32), camera[1], camera[2])
         want = s.render(max_depth=max_depth)
     finally:
         s.close()
@@ -59,6 +64,7 @@ def render_and_compare(emu_render, scene_text, model_dir, work, max_depth, queue
     assert np.fromfile(out + ".counters", dtype=np.uint64)[:5].tolist() == [int(x) for x in want["counters"][:5]]
     diff = np.abs(np.fromfile(out + ".rgb", dtype=np.uint8).reshape(h, w, 3).astype(int) - want["rgb"].astype(int)).max(axis=2)
     assert (diff <= 1).mean() >= 0.98, (diff <= 1).mean()
+    render_and_compare.last_counters = np.fromfile(out + ".counters", dtype=np.uint64)
     return int(want["counters"][0])
 
 
@@ -112,6 +118,26 @@ def test_result_only_entries_are_not_walked(emu_render, tmp_path):
         if seed == 9019:
             assert any(x.startswith("soup") for x in what), what
         render_and_compare(emu_render, text, d, str(work), depth)
+
+
+def test_rays_from_far_away(emu_render, tmp_path):
+    """synthetic.far_origin_scene: rays that start 2^21 units away on every axis pass whatever box of a mesh comes near them, and the reference tests
+    nearly every triangle for each of them.  The library takes such (ray, instance) pairs out of the lane-by-lane walk and
+    has a block test all leaves side by side (traverse_heavy_pairs) - up to a number per depth, which this frame exceeds, so
+    both ways of computing a pair run here and must give the reference's hit, t and colour."""
+    from rust_raytracer_amd import abi
+    d = str(tmp_path)
+    text, cameras = synthetic.far_origin_scene(d, 4)
+    heavy, tests = [], []
+    for k, camera in enumerate(cameras):
+        work = tmp_path / str(k)
+        work.mkdir()
+        render_and_compare(emu_render, text, d, str(work), 3, camera=camera)
+        c = render_and_compare.last_counters
+        heavy.append(int(c[abi.RT_CTR_WALK_HEAVY_PAIRS]))
+        tests.append(int(c[abi.RT_CTR_WALK_TRIANGLE_TESTS]))
+    assert heavy[0] >= 1024 and heavy[1] > 0, heavy                   # the first frame has more such pairs than are taken per depth
+    assert tests[0] > 50 * heavy[0], (tests, heavy)                   # the diagonal rays do pass a good many leaves each
 
 
 def test_tree_whose_boxes_do_not_nest(emu_render, scenes_dir, model_dir, tmp_path):
