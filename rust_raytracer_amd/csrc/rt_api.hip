@@ -78,6 +78,7 @@ struct RtScene {
     bool must_grow = false;             // a frame overflowed: the next one needs lists longer than it had
     uint32_t noalloc_seq_lo = 1, noalloc_seq_hi = 0;     // sequence numbers of the latest run of rt_render_device_noalloc frames
     uint32_t walk_contiguous = 0;       // see DFrame::walk_contiguous
+    uint32_t walk_packet_levels = 0;    // see DFrame::walk_packet_levels (RT_WALK_PACKET_LEVELS)
     void* scratch = nullptr;            // this device's copy of the static scratch array (rt_render_device_noalloc)
     uint32_t regrown = 0;               // times rt_render had to enlarge the lists for its last frame
     std::vector<void*> scene_allocs;
@@ -590,6 +591,9 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device_id, RtScene**
     // (0: never, 1: always, 2: launch by launch, where a wave gets several chunks - see rt_traverse)
     s->walk_contiguous = (nodes4.size() + hot.size()) * sizeof(float4) > (64u << 20) ? 1u : 2u;
     if (const char* env = getenv("RT_WALK_CONTIGUOUS")) { const int v = atoi(env); if (v >= 0 && v <= 2) s->walk_contiguous = (uint32_t)v; }
+    // The packet walk (rt_traverse_packet) is measured slower than the lane-by-lane walk at every depth of every workload
+    // tried, the coherent first two included, so no launch uses it unless asked to.
+    if (const char* env = getenv("RT_WALK_PACKET_LEVELS")) { const int v = atoi(env); if (v >= 0 && v <= RT_MAX_DEPTH_LIMIT + 1) s->walk_packet_levels = (uint32_t)v; }
     s->h_overflow[0] = 0;
     s->h_overflow[1] = 0;
     // In a scene whose instances all have culling boxes only stray rays (non-finite or huge components) need the exact
@@ -741,7 +745,14 @@ static void fill_frame(const RtScene* s, const Geometry& g, uint32_t max_depth, 
     f->needs_slow = s->d_overflow + 1;
     f->slow_launched = s->slow_enabled ? 1u : 0u;
     f->walk_contiguous = s->walk_contiguous;
+    f->walk_packet_levels = s->walk_packet_levels;
     f->fuse_setup = s->fuse_setup;
+}
+
+// Stack entries per walking lane kept in device memory: what a walk can need beyond the entries in LDS - and, where packet
+// walks are in use, what a lane may put aside during a packet (RT_PACKET_ASIDE in rt_kernels.hip).
+static uint32_t spill_entries(const RtScene* s) {
+    return s->d.stack_entries - s->d.stack_lds + (s->walk_packet_levels ? 32u : 0u);
 }
 
 static int ensure_frame(RtScene* s, const Geometry& g, uint32_t max_depth, bool aux) {
@@ -785,7 +796,7 @@ static int ensure_frame(RtScene* s, const Geometry& g, uint32_t max_depth, bool 
             s->frame_allocs.push_back(*p);
             return (int)RT_OK;
         };
-        int rc = carve_frame(g.n_pixels, s->d.n_lights, blocks, capacity, seg_min, aux, s->d.stack_entries - s->d.stack_lds,
+        int rc = carve_frame(g.n_pixels, s->d.n_lights, blocks, capacity, seg_min, aux, spill_entries(s),
                              s->traverse_blocks * 256u, take, &s->f, &sz);
         if (rc) return rc;
         s->stats_words = sz.stats_words;
@@ -873,7 +884,7 @@ static int enqueue_frame(RtScene* s, const RtRenderParams* p, bool sharded, bool
             return (int)RT_OK;
         };
         const uint64_t capacity = std::max<uint64_t>((uint64_t)8 * g.n_pixels, 4096);
-        if ((rc = carve_frame(g.n_pixels, s->d.n_lights, blocks, capacity, 64u, false, s->d.stack_entries - s->d.stack_lds,
+        if ((rc = carve_frame(g.n_pixels, s->d.n_lights, blocks, capacity, 64u, false, spill_entries(s),
                               s->traverse_blocks * 256u, take, &f, &sz))) return rc;
         if (used > RT_NOALLOC_SCRATCH_BYTES)
             return fail(RT_ERR_OUT_OF_RANGE,

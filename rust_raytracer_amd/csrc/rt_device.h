@@ -197,6 +197,7 @@ struct DFrame {
     uint2* spill;                    // traversal stack entries beyond DScene::stack_lds: entry e of walking lane g at [e * spill_lanes + g]
     uint32_t spill_lanes;            // lanes of the BVH walk's grid
     uint32_t walk_contiguous;        // the walk hands out runs of neighbouring pairs instead of interleaving them: 0 never, 1 always, 2 in launches with several chunks per wave
+    uint32_t walk_packet_levels;     // the BVH walks of the depths below this number run as packet walks (rt_traverse_packet)
     uint32_t fuse_setup;             // rt_shade sets up the rays it makes (rt_setup only runs at depth 0)
     unsigned int* chunk_counter;     // [RT_MAX_DEPTH_LIMIT + 2] input chunks of the BVH walk handed out so far, per depth
     unsigned int* heavy_count;       // [RT_MAX_DEPTH_LIMIT + 2] pairs on the depth's list for traverse_heavy_pairs (may exceed RT_HEAVY_CAP: the rest are walked)

@@ -1735,6 +1735,261 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse(const DScene S, 
 }
 
 // ======================================================================================================
+// Kernel B as a packet walk: the wave walks the tree for all its pairs of one instance together while they agree on where
+// to go, and lane by lane from where they part.  A wave takes 64 neighbouring walk items - at depth 0 the pairs of an
+// 8 x 8 pixel block with an instance lie next to each other, at depth 1 the shadow rays of such a block's hits - and
+// groups them by the tree they walk.  For a group the current node is wave-uniform: its 128 bytes arrive through scalar
+// loads, once for all lanes, the four boxes are operands from scalar registers, each lane tests them for its own ray
+// against its own distance bound, and a child is visited by the packet if enough lanes want it (`__ballot`); a child
+// fewer lanes want goes onto those lanes' own stacks, and when the packet has nothing left every lane walks what it
+// has collected on its own, as rt_traverse does.  The candidates a lane sees are those of its own walk in another
+// order - a box is tested with the lane's own ray, a leaf's triangles only by the lanes whose ray passed the leaf's box -
+// and the closest one by (t, slot) does not depend on the order (see rt_traverse).
+// Which launches use it: DFrame::walk_packet_levels (the depths below that number).
+// ======================================================================================================
+#ifndef RT_PACKET_MIN
+#define RT_PACKET_MIN 16           // lanes that have to want a node for the packet to visit it
+#endif
+#define RT_PACKET_ASIDE 32         // entries a lane may put aside before the wave walks them (DFrame::spill is sized for it)
+// A read of scene data at a wave-uniform address, as a scalar load: the compiler only issues one when it knows the memory
+// cannot change under the kernel, which the constant address space tells it (the scene arrays are written once, by
+// rt_scene_create).
+#if defined(__clang__) && defined(__HIP_DEVICE_COMPILE__) && !defined(RT_NO_SCALAR_LOADS)
+typedef const float4 __attribute__((address_space(4))) RtUniformFloat4;
+#define RT_UNIFORM_FLOAT4(p) ((RtUniformFloat4*)(p))
+#else
+#define RT_UNIFORM_FLOAT4(p) (p)
+#endif
+
+#ifdef RT_PACKET_WAVES
+__attribute__((amdgpu_waves_per_eu(RT_PACKET_WAVES, RT_PACKET_WAVES)))
+#endif
+__global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse_packet(const DScene S, const DFrame F, const uint32_t level) {
+    const LevelLists L = level_lists(F, level);
+    {
+        const uint32_t heavy_blocks = gridDim.x < RT_HEAVY_BLOCKS ? gridDim.x : RT_HEAVY_BLOCKS;
+        if (blockIdx.x < heavy_blocks && *L.heavy_count != 0) traverse_heavy_pairs(S, F, level, heavy_blocks);
+    }
+    extern __shared__ uint32_t lds[];
+    uint32_t* pre = lds;
+    uint32_t* scratch = lds + F.n_seg + 1;
+    const uint32_t n_items = build_prefix(L.fat_counts, F.n_seg, F.seg_fat, F.ovf_fat, pre, scratch);
+    const uint32_t lane = threadIdx.x & (RT_WAVE - 1), wave = threadIdx.x / RT_WAVE, waves_per_block = blockDim.x / RT_WAVE;
+    const uint32_t stack_lds = S.stack_lds, stack_entries = S.stack_entries;
+    uint32_t* stack = lds + F.n_seg + 1 + blockDim.x + wave * (2 * stack_lds * RT_WAVE) + lane;       // this lane's own stack, as in rt_traverse
+    uint32_t* stack_t = stack + stack_lds * RT_WAVE;
+    uint2* spill = F.spill + (blockIdx.x * blockDim.x + threadIdx.x);
+    const size_t spill_lanes = F.spill_lanes;
+    // the packet's stack, one per wave: entry e = {reference, the lanes that want it (two words)}
+    uint32_t* ustack = lds + F.n_seg + 1 + blockDim.x + waves_per_block * (2 * stack_lds * RT_WAVE) + wave * (3 * (stack_entries + 1));
+    const uint32_t gwave = (blockIdx.x * blockDim.x + threadIdx.x) / RT_WAVE;
+    const uint32_t n_waves = gridDim.x * waves_per_block;
+    const uint32_t n_chunks = (n_items + RT_WAVE - 1) / RT_WAVE;
+    uint32_t n_node_visits = 0, n_triangle_tests = 0;
+
+    uint32_t sp = 0;
+    // A lane's own stack holds what it has put aside during the packet - at most RT_PACKET_ASIDE entries, then the wave
+    // stops to walk them - plus what a depth-first walk of one of them can need.
+    const uint32_t own_entries = stack_entries + RT_PACKET_ASIDE;
+    auto push_own = [&](uint32_t ref, float t) {
+        if (sp < stack_lds) { stack[sp * RT_WAVE] = ref; stack_t[sp * RT_WAVE] = __float_as_uint(t); }
+        else if (sp < own_entries) spill[(sp - stack_lds) * spill_lanes] = make_uint2(ref, __float_as_uint(t));
+        else *F.overflow = F.overflow_seq;
+        ++sp;
+    };
+
+    for (uint32_t c = gwave; c < n_chunks;) {
+        const uint32_t v = c * RT_WAVE + lane;
+        bool valid = v < n_items;
+        const uint32_t fat = locate_run(pre, F.n_seg, F.seg_fat, c * RT_WAVE, lane, valid, lane);
+        float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
+        if (valid) { q0 = L.fat_items[4 * (size_t)fat]; q1 = L.fat_items[4 * (size_t)fat + 1]; q2 = L.fat_items[4 * (size_t)fat + 2]; q3 = L.fat_items[4 * (size_t)fat + 3]; }
+        valid = valid && !(__float_as_uint(q3.y) & (RT_FAT_DONE | RT_FAT_HEAVY));
+        Ray lr;
+        lr.o = mk(q0.x, q0.y, q0.z);
+        lr.d = mk(q1.x, q1.y, q1.z);
+        const V3 inv = mk(1.0f / lr.d.x, 1.0f / lr.d.y, 1.0f / lr.d.z);
+        const float limit = q1.w, inv_dn = q2.x, shadow_thr = q2.y, prune_abs = q2.z;
+        const uint32_t gi = __float_as_uint(q3.x), ii = __float_as_uint(q3.y) & RT_FAT_INSTANCE, root_ref = __float_as_uint(q2.w);
+        const bool fast = (__float_as_uint(q3.y) & RT_FAT_FAST) != 0;
+        bool m_have = false; float m_t = 0.0f, m_u = 0.0f, m_v = 0.0f; uint32_t m_slot = 0;
+        bool proven = false;                                  // a shadow ray that is known to be blocked (see walk_item)
+        sp = 0;
+
+        // the candidate test of a leaf's triangle, as in rt_traverse
+        auto test_triangle = [&](const float4 h0, const float4 h1, const float4 h2, uint32_t slot) {
+            float t, u, w;
+            if (triangle_tuv(mk(h0.x, h0.y, h0.z), mk(h0.w, h1.x, h1.y), mk(h1.z, h1.w, h2.x), lr, t, u, w) &&
+                (!m_have || t < m_t || (t == m_t && slot < m_slot))) {
+                m_have = true; m_t = t; m_u = u; m_v = w; m_slot = slot;
+                if (m_t * inv_dn < shadow_thr) proven = true;
+            }
+        };
+        auto current_cut = [&]() {
+            if (!fast) return RT_INF;
+            const float lim = (m_have && m_t < limit) ? m_t : limit;
+            return lim * RT_PRUNE_REL + prune_abs;
+        };
+
+        // ---- lane by lane: what the lanes have put aside on their own stacks -------------------------------------------
+        auto walk_own = [&]() {
+            if (proven) sp = 0;                                         // (a blocked shadow ray needs nothing further)
+            while (__ballot(sp != 0 && !proven)) {
+                if (sp == 0 || proven) continue;
+                --sp;
+                uint32_t ref; float et;
+                if (sp < stack_lds) { ref = stack[sp * RT_WAVE]; et = __uint_as_float(stack_t[sp * RT_WAVE]); }
+                else if (sp < own_entries) { const uint2 e = spill[(sp - stack_lds) * spill_lanes]; ref = e.x; et = __uint_as_float(e.y); }
+                else continue;                                                  // (an entry push_own dropped)
+                const float cut = current_cut();
+                if (et > cut) continue;
+                if (ref & RT_REF_LEAF_BIT) {
+                    const uint32_t first = ref & RT_REF_SLOT_MASK, cnt = (ref >> RT_REF_COUNT_SHIFT) & 7u;
+                    n_triangle_tests += cnt;
+                    for (uint32_t j = 0; j < cnt; ++j) {
+                        const uint32_t slot = first + j;
+                        test_triangle(S.tri_hot[3 * slot], S.tri_hot[3 * slot + 1], S.tri_hot[3 * slot + 2], slot);
+                    }
+                    continue;
+                }
+                ++n_node_visits;
+                const float4* nq = S.nodes4 + 8 * (size_t)ref;
+                const float4 nd0 = nq[0], nd1 = nq[1], nd2 = nq[2], nd3 = nq[3], nd4 = nq[4], nd5 = nq[5], nd6 = nq[6];
+                float t0, t1, t2, t3;
+                const bool h0 = slab(nd0.x, nd0.y, nd0.z, nd0.w, nd1.x, nd1.y, lr.o, inv, t0);
+                const bool h1 = slab(nd1.z, nd1.w, nd2.x, nd2.y, nd2.z, nd2.w, lr.o, inv, t1);
+                const bool h2 = slab(nd3.x, nd3.y, nd3.z, nd3.w, nd4.x, nd4.y, lr.o, inv, t2);
+                const bool h3 = slab(nd4.z, nd4.w, nd5.x, nd5.y, nd5.z, nd5.w, lr.o, inv, t3);
+                uint32_t r0 = (h0 && !(t0 > cut)) ? __float_as_uint(nd6.x) : RT_REF_NONE;
+                uint32_t r1 = (h1 && !(t1 > cut)) ? __float_as_uint(nd6.y) : RT_REF_NONE;
+                uint32_t r2 = (h2 && !(t2 > cut)) ? __float_as_uint(nd6.z) : RT_REF_NONE;
+                uint32_t r3 = (h3 && !(t3 > cut)) ? __float_as_uint(nd6.w) : RT_REF_NONE;
+                if (fast) {
+                    t0 = r0 == RT_REF_NONE ? RT_INF : t0; t1 = r1 == RT_REF_NONE ? RT_INF : t1;
+                    t2 = r2 == RT_REF_NONE ? RT_INF : t2; t3 = r3 == RT_REF_NONE ? RT_INF : t3;
+#define RT_CSWAP(ta, ra, tb, rb) { const bool sw = tb < ta; const float tt = sw ? ta : tb; ta = sw ? tb : ta; tb = tt; \
+                                       const uint32_t rt_ = sw ? ra : rb; ra = sw ? rb : ra; rb = rt_; }
+                    RT_CSWAP(t0, r0, t1, r1) RT_CSWAP(t2, r2, t3, r3) RT_CSWAP(t0, r0, t2, r2) RT_CSWAP(t1, r1, t3, r3) RT_CSWAP(t1, r1, t2, r2)
+#undef RT_CSWAP
+                }
+                if (r3 != RT_REF_NONE) push_own(r3, t3);                    // the last one deepest
+                if (r2 != RT_REF_NONE) push_own(r2, t2);
+                if (r1 != RT_REF_NONE) push_own(r1, t1);
+                if (r0 != RT_REF_NONE) push_own(r0, t0);
+            }
+            if (proven) sp = 0;
+        };
+
+        // ---- the packets: one per tree among the chunk's pairs --------------------------------------------------------
+        bool grouped = !valid;
+        for (;;) {
+            const unsigned long long todo = __ballot(!grouped);
+            if (!todo) break;
+            const uint32_t leader = __ffsll((long long)todo) - 1;
+            const uint32_t root = __builtin_amdgcn_readfirstlane((uint32_t)__shfl((int)root_ref, (int)leader));
+            const bool in_group = !grouped && root_ref == root;
+            const unsigned long long gmask = __ballot(in_group);
+            grouped = grouped || in_group;
+            if ((uint32_t)__popcll(gmask) < RT_PACKET_MIN || root == RT_REF_NONE) {
+                if (in_group && root != RT_REF_NONE) push_own(root_ref, q0.w);
+                continue;
+            }
+            uint32_t usp = 0;
+            if (lane == 0) { ustack[0] = root; ustack[1] = (uint32_t)gmask; ustack[2] = (uint32_t)(gmask >> 32); }
+            usp = 1;
+            __builtin_amdgcn_wave_barrier();
+            while (usp) {
+                --usp;
+                const uint32_t ref = (uint32_t)__builtin_amdgcn_readfirstlane(ustack[3 * usp]);
+                // (the builtin returns a signed int: without the casts a low word with its top bit set would spill over the high one)
+                const unsigned long long m = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane(ustack[3 * usp + 1]) |
+                                             ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane(ustack[3 * usp + 2]) << 32);
+                const bool act = ((m >> lane) & 1ull) && !proven;
+                if (ref & RT_REF_LEAF_BIT) {
+                    const uint32_t first = ref & RT_REF_SLOT_MASK, cnt = (ref >> RT_REF_COUNT_SHIFT) & 7u;
+                    if (act) n_triangle_tests += cnt;
+                    for (uint32_t j = 0; j < cnt; ++j) {
+                        const uint32_t slot = first + j;                                        // wave-uniform: scalar loads
+                        const auto* hq = RT_UNIFORM_FLOAT4(S.tri_hot + 3 * (size_t)slot);
+                        const float4 h0 = hq[0], h1 = hq[1], h2 = hq[2];
+                        if (act) test_triangle(h0, h1, h2, slot);
+                    }
+                    continue;
+                }
+                // the node's 128 bytes through scalar loads (a wave-uniform address), once for all lanes
+                const auto* nq = RT_UNIFORM_FLOAT4(S.nodes4 + 8 * (size_t)ref);
+                const float4 nd0 = nq[0], nd1 = nq[1], nd2 = nq[2], nd3 = nq[3], nd4 = nq[4], nd5 = nq[5], nd6 = nq[6];
+                if (act) ++n_node_visits;
+                const float cut = current_cut();
+                float t[4];
+                bool pass[4];
+                pass[0] = slab(nd0.x, nd0.y, nd0.z, nd0.w, nd1.x, nd1.y, lr.o, inv, t[0]);
+                pass[1] = slab(nd1.z, nd1.w, nd2.x, nd2.y, nd2.z, nd2.w, lr.o, inv, t[1]);
+                pass[2] = slab(nd3.x, nd3.y, nd3.z, nd3.w, nd4.x, nd4.y, lr.o, inv, t[2]);
+                pass[3] = slab(nd4.z, nd4.w, nd5.x, nd5.y, nd5.z, nd5.w, lr.o, inv, t[3]);
+                const uint32_t refs[4] = {__float_as_uint(nd6.x), __float_as_uint(nd6.y), __float_as_uint(nd6.z), __float_as_uint(nd6.w)};
+                unsigned long long want[4];
+                uint32_t near_key[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    pass[k] = act && refs[k] != RT_REF_NONE && pass[k] && !(t[k] > cut);
+                    want[k] = __ballot(pass[k]);
+                    // how near the child is, for the order of the visits: the smallest entry distance among the lanes that want
+                    // it would be best; the first such lane's is what a packet can have for one lane read
+                    const uint32_t who = want[k] ? (uint32_t)__ffsll((long long)want[k]) - 1 : 0u;
+                    const float tk = __shfl(t[k], (int)who);
+                    near_key[k] = want[k] ? (tk > 0.0f ? __builtin_amdgcn_readfirstlane(__float_as_uint(tk)) : 0u) : 0xFFFFFFFFu;
+                }
+                // far children first onto the stack, so that the nearest is popped first (the order only decides how soon the
+                // lanes' distance bounds bite); a child few lanes want goes onto their own stacks
+                uint32_t done_mask = 0;
+#pragma unroll
+                for (int round = 0; round < 4; ++round) {
+                    int far = -1;
+                    uint32_t far_key = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (!((done_mask >> k) & 1u) && want[k] && (far < 0 || near_key[k] >= far_key)) { far = k; far_key = near_key[k]; }
+                    if (far < 0) break;
+                    done_mask |= 1u << far;
+                    const unsigned long long wm = far == 0 ? want[0] : far == 1 ? want[1] : far == 2 ? want[2] : want[3];
+                    const uint32_t wr = far == 0 ? refs[0] : far == 1 ? refs[1] : far == 2 ? refs[2] : refs[3];
+                    if ((uint32_t)__popcll(wm) >= RT_PACKET_MIN) {
+                        if (usp <= stack_entries) {
+                            if (lane == 0) { ustack[3 * usp] = wr; ustack[3 * usp + 1] = (uint32_t)wm; ustack[3 * usp + 2] = (uint32_t)(wm >> 32); }
+                            ++usp;
+                        } else *F.overflow = F.overflow_seq;
+                    } else {
+                        const bool mine = far == 0 ? pass[0] : far == 1 ? pass[1] : far == 2 ? pass[2] : pass[3];
+                        const float mt = far == 0 ? t[0] : far == 1 ? t[1] : far == 2 ? t[2] : t[3];
+                        if (mine) push_own(wr, mt);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (__ballot(sp + 4 > RT_PACKET_ASIDE)) walk_own();     // (every lane's stack is empty afterwards)
+            }
+        }
+        walk_own();
+
+        // ---- the pairs' closest hits join their rays' other candidates (scene.rs:133-136), as in rt_traverse ---------------
+        if (valid && m_have) {
+            const float tw = world_t(S, S.instances[ii], lr, load_any_origin(S, F, level, gi), m_t, m_slot);
+            L.item_results[fat] = make_float4(m_t, m_u, m_v, __uint_as_float(m_slot));
+            atomicMin(&L.best[gi], make_key(tw, RT_KEY_MESH | fat));
+        }
+        // the next chunk: the wave's own first, further ones from the depth's counter
+        uint32_t taken = 0;
+        if (lane == 0) taken = atomicAdd(&F.chunk_counter[level], 1u);
+        c = n_waves + __builtin_amdgcn_readfirstlane(taken);
+    }
+    {
+        uint32_t a = n_node_visits, b = n_triangle_tests;
+        for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
+        if (lane == 0 && (a | b)) { F.wave_stats[(size_t)gwave * 8 + 5] += a; F.wave_stats[(size_t)gwave * 8 + 6] += b; }
+    }
+}
+
+// ======================================================================================================
 // Second half of kernel C: the Phong sum of shade_phong / radiance (raytracer.rs:75-84, 137-153) for the hits
 // of the previous depth, now that their shadow rays have been traced.  Block-wide (it builds a prefix table).
 // ======================================================================================================
@@ -2107,6 +2362,12 @@ static size_t traverse_lds_bytes(uint32_t n_seg, uint32_t stack_entries) {
            (size_t)(RT_BLOCK_THREADS / RT_WAVE) * 2 * stack_entries * RT_WAVE * sizeof(uint32_t) + 16 + (size_t)RT_BLOCK_THREADS * 16;
 }
 
+static size_t packet_lds_bytes(uint32_t n_seg, uint32_t stack_lds, uint32_t stack_entries) {
+    // as the walk's, without the pair records, plus the packets' stacks (three words per entry, one stack per wave)
+    return (size_t)(n_seg + 1 + RT_BLOCK_THREADS) * sizeof(uint32_t) +
+           (size_t)(RT_BLOCK_THREADS / RT_WAVE) * (2 * stack_lds * RT_WAVE + 3 * (stack_entries + 1)) * sizeof(uint32_t);
+}
+
 // Resident blocks of the traversal kernel per compute unit (registers and the LDS stacks decide).
 extern "C" int rt_query_traverse_blocks_per_cu(uint32_t n_seg, uint32_t stack_entries) {
     int n = 0;
@@ -2144,7 +2405,10 @@ extern "C" hipError_t rt_launch_level(const DScene* S, const DFrame* F, uint32_t
         hipLaunchKernelGGL(rt_setup_slow, dim3(slow_blocks), dim3(RT_BLOCK_THREADS), lds + analytic_stage_words(*S) * sizeof(uint32_t), stream,
                            *S, *F, level);
     if (marks) (void)hipEventRecord(marks[1], stream);
-    if (S->n_instances > 0)
+    if (S->n_instances > 0 && level < F->walk_packet_levels)
+        hipLaunchKernelGGL(rt_traverse_packet, dim3(traverse_blocks), dim3(RT_BLOCK_THREADS),
+                           packet_lds_bytes(F->n_seg, S->stack_lds, S->stack_entries), stream, *S, *F, level);
+    else if (S->n_instances > 0)
         hipLaunchKernelGGL(rt_traverse, dim3(traverse_blocks), dim3(RT_BLOCK_THREADS), traverse_lds_bytes(F->n_seg, S->stack_lds),
                            stream, *S, *F, level);
 #ifdef RT_STATS

@@ -78,10 +78,10 @@ template <class T> static inline T __shfl_down(T v, unsigned int delta) {
     if (l + delta >= 64) return v;
     return ((live >> (l + delta)) & 1) ? emu_from_bits<T>(s[l + delta]) : v;
 }
-static inline unsigned int __builtin_amdgcn_readfirstlane(unsigned int v) {
+static inline int __builtin_amdgcn_readfirstlane(int v) {           // (signed, as the compiler's builtin is)
     unsigned long long live;
-    const unsigned long long* s = emu::wave_exchange(v, &live);
-    return (unsigned int)s[__builtin_ctzll(live)];
+    const unsigned long long* s = emu::wave_exchange((unsigned int)v, &live);
+    return (int)(unsigned int)s[__builtin_ctzll(live)];
 }
 // DPP operand: the lane reads `v` of another lane of its row.  The controls the kernels use: quad permutes (0x00-0xFF, two
 // bits per lane of the quad), row_mirror (0x140), row_half_mirror (0x141).

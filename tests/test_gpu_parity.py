@@ -208,6 +208,69 @@ def test_instance_grid_2p6m_triangles_at_4k(tmp_path_factory):
     assert (got["prim_id"] >> 30 == abi.RT_PRIM_MESH_TRIANGLE).sum() > 1_000_000
 
 
+def test_instance_grid_10m_triangles_at_4k(tmp_path_factory):
+    """The many-mesh configuration at its stated size: 256 instances over 128 distinct meshes of 81 920 triangles
+    (10.5 M triangles; the scenes with more than 16 instances walk the range tree over instances) at 3840x2160 - every
+    pixel against the oracle."""
+    from rust_raytracer_amd import synthetic
+    d = str(tmp_path_factory.mktemp("grid_models_10m"))
+    s = orc.OracleScene.from_text(synthetic.instance_grid_scene(d, 16, 128, 6, 3840, 2160), d)
+    assert s.desc().n_mesh_triangles == 128 * 81920
+    got, want = render_both(s)
+    exact, within = assert_parity(got, want)
+    print("instance grid 10.5 M triangles 3840x2160: %d rays, %.5f identical, %.5f within 1 LSB" % (int(got["counters"][0]), exact, within))
+    assert (got["prim_id"] >> 30 == abi.RT_PRIM_MESH_TRIANGLE).sum() > 1_000_000
+
+
+def test_orbit_batch_of_32_views_at_1080p(scenes_dir, model_dir):
+    """The batch-of-views configuration at full frame size: 32 poses on a circle around the headline scene at 1920x1080,
+    handed over sixteen at a time (rt_scene_set_views), the two passes in flight together on two handles and two streams
+    (rt_render_device) - every view's picture against the oracle's, the passes' ray counts against the sum of the
+    oracle's; then the first sixteen once more through rt_render with the per-pixel ids, flags and t of every view."""
+    import torch
+    from rust_raytracer_amd import synthetic
+    s = load(scenes_dir, model_dir, "reflective_bunnies", 1920, 1080)
+    host = native.HostScene.load(os.path.join(scenes_dir, "reflective_bunnies.json"), model_dir)
+    host.resize_screen(1920, 1080)
+    mats = []
+    for position, orientation in synthetic.orbit_poses(32, centre=(0.0, 0.0, -6.0)):
+        host.set_camera_pose(position, orientation)
+        m, w, h = host.camera()
+        mats.append(np.asarray(m, dtype=np.float32).reshape(16))
+    want = []
+    for m in mats:
+        s.set_camera_matrix(m, w, h)
+        want.append(s.render())
+    devs = [native.DeviceScene(host.desc(), 0) for _ in range(2)]
+    try:
+        streams = [torch.cuda.Stream() for _ in range(2)]
+        bufs = [torch.zeros(16 * h * w * 3, dtype=torch.uint8, device="cuda") for _ in range(2)]
+        for attempt in range(4):                                        # (poses that send rays onto the exact path make a handle redo its first pass)
+            for k in range(2):
+                devs[k].set_views(np.stack(mats[16 * k:16 * k + 16]), w, h)
+                devs[k].render_device(bufs[k].data_ptr(), stream=streams[k].cuda_stream)
+            torch.cuda.synchronize()
+            try:
+                counts = [devs[k].last_ray_counts() for k in range(2)]
+                break
+            except native.RtError:
+                if attempt == 3:
+                    raise
+        for k in range(2):
+            got = bufs[k].cpu().numpy().reshape(16, h, w, 3)
+            for v in range(16):
+                diff = np.abs(got[v].astype(int) - want[16 * k + v]["rgb"].astype(int)).max(axis=2)
+                assert (diff <= 1).mean() >= 0.999, (k, v, (diff <= 1).mean())
+            assert counts[k][:5].tolist() == sum(np.asarray(x["counters"][:5], dtype=np.int64) for x in want[16 * k:16 * k + 16]).tolist()
+        together = devs[0].render(aux=True)
+        for v in range(16):
+            assert_parity({key: together[key][v] for key in ("rgb", "prim_id", "instance_id", "flags", "hit_t")} | {"counters": want[v]["counters"]}, want[v])
+    finally:
+        for d in devs:
+            d.close()
+        host.close()
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2])
 def test_pruning_bound_adversarial(tmp_path_factory, seed):
     """synthetic.pruning_stress_scene: a mesh that is walked with distance pruning (|e1||e2| = 0.1225, bound 0.125) seen
@@ -234,6 +297,27 @@ def test_pruning_bound_adversarial(tmp_path_factory, seed):
         assert sliver_hits == 6                      # every sliver wins somewhere
     finally:
         dev.close()
+
+
+@pytest.mark.parametrize("levels", [2, 64])
+def test_packet_walk(scenes_dir, model_dir, tmp_path_factory, monkeypatch, levels):
+    """The BVH walks of the first two depths, or of all, as packet walks (rt_traverse_packet: a wave's pairs of one instance
+    walk the top of the tree together - scalar node loads, one ballot per child - and go on lane by lane from where they
+    part): hits, t and colours are those of the reference on the headline scene, on an instance grid over several meshes
+    and on a frame whose lists are too short at first."""
+    from rust_raytracer_amd import synthetic
+    monkeypatch.setenv("RT_WALK_PACKET_LEVELS", str(levels))            # read when the scene handle is created
+    s = load(scenes_dir, model_dir, "reflective_bunnies", 480, 270)
+    got, want = render_both(s)
+    assert_parity(got, want)
+    assert (got["prim_id"] >> 30 == abi.RT_PRIM_MESH_TRIANGLE).sum() > 480 * 270 // 40
+    got, want = render_both(s, queue_capacity=30000)
+    assert got["regrown"] >= 1
+    assert_parity(got, want)
+    d = str(tmp_path_factory.mktemp("packet_grid"))
+    g = orc.OracleScene.from_text(synthetic.instance_grid_scene(d, 4, 4, 3, 320, 180), d)
+    got, want = render_both(g)
+    assert_parity(got, want)
 
 
 def test_rays_from_far_away(tmp_path_factory):

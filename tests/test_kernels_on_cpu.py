@@ -32,7 +32,7 @@ def emu_render():
     return os.path.join(EMU, "emu_render")
 
 
-def render_and_compare(emu_render, scene_text, model_dir, work, max_depth, queue_capacity=0, shrink_bvh=False, camera=None):
+def render_and_compare(emu_render, scene_text, model_dir, work, max_depth, queue_capacity=0, shrink_bvh=False, camera=None, packet_levels=0):
     path = os.path.join(work, "scene.json")
     with open(path, "w") as f:
         f.write(scene_text)
@@ -44,6 +44,8 @@ def render_and_compare(emu_render, scene_text, model_dir, work, max_depth, queue
         env["EMU_QUEUE_CAPACITY"] = str(queue_capacity)
     if shrink_bvh:
         env["EMU_SHRINK_BVH"] = "1"
+    if packet_levels:
+        env["RT_WALK_PACKET_LEVELS"] = str(packet_levels)             # the BVH walks of the first depths as packet walks
     out = os.path.join(work, "out")
     r = subprocess.run([emu_render, model_dir, str(max_depth), path, out], capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stderr[-4000:]                       # a sanitizer report ends up here
@@ -138,6 +140,20 @@ def test_rays_from_far_away(emu_render, tmp_path):
         tests.append(int(c[abi.RT_CTR_WALK_TRIANGLE_TESTS]))
     assert heavy[0] >= 1024 and heavy[1] > 0, heavy                   # the first frame has more such pairs than are taken per depth
     assert tests[0] > 50 * heavy[0], (tests, heavy)                   # the diagonal rays do pass a good many leaves each
+
+
+def test_packet_walk(emu_render, scenes_dir, model_dir, tmp_path):
+    """The BVH walks of the first depths (or of all) as packet walks - rt_traverse_packet: a wave's pairs of one instance walk
+    the top of the tree together through scalar node loads and ballots, then lane by lane - give the picture, the hit
+    triangles and the t of the lane-by-lane walk: on the headline scene, on a scene of random instances and materials, and
+    with lists so short that the frame is rendered again."""
+    for k, (text, d, depth, levels, capacity) in enumerate([
+            (small(scenes_dir, "reflective_bunnies", 72, 40), model_dir, 5, 2, 0),
+            (small(scenes_dir, "reflective_bunnies", 72, 40), model_dir, 4, 64, 900),
+            (synthetic.random_scene(str(tmp_path), 11, 64, 40), str(tmp_path), 4, 64, 0)]):
+        work = tmp_path / ("packet%d" % k)
+        work.mkdir()
+        render_and_compare(emu_render, text, d, str(work), depth, capacity, packet_levels=levels)
 
 
 def test_tree_whose_boxes_do_not_nest(emu_render, scenes_dir, model_dir, tmp_path):
