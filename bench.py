@@ -313,6 +313,8 @@ def main():
     elapsed = float(np.median(regions))
     # ray counts of every pass (raises if any frame since the set-up overflowed its ray lists: the report is sticky)
     slot_counts = [s.dev.last_ray_counts().astype(np.int64)[:5] for s in every_slot]
+    # device memory behind the work lists and colour sums of one pass in flight (sized by what the set-up passes held)
+    list_use = slots[0].dev.last_list_use()
     counts = sum(slot_counts[k % depth] for k in range(passes))
     if last_slot:
         counts = counts + slot_counts[-1]
@@ -504,6 +506,7 @@ def main():
                        "rays_per_frame": rays_per_frame, "primary": int(frame_rays[1]), "shadow": int(frame_rays[2]),
                        "reflected": int(frame_rays[3]), "transmitted": int(frame_rays[4]),
                        "frames_in_flight": depth * views, "passes_in_flight": depth, "views_per_pass": views,
+                       "list_bytes_per_pass": list_use["bytes"], "list_bytes_per_view": list_use["bytes"] // max(views, 1),
                        "parallelism": ("tile-sharded x%d, scene replicated, %s" % (world, "REHEARSAL: ranks share one GPU, gloo"
                                        if args.rehearse_on_one_gpu else "RCCL all-gather")) if world > 1 else
                                       ("single GPU, every pass through an RCCL all-gather of world size 1" if args.exercise_collective else "single GPU")},

@@ -39,6 +39,7 @@ use crate::Scene;
 #[repr(C)] pub struct RtRenderParams { pub max_depth: u32, pub output_format: u32, pub shard_index: u32, pub shard_count: u32,
                                        pub mode: u32, pub reserved: u32, pub stream: *mut c_void }
 pub const RT_N_COUNTERS: usize = 16;
+pub const RT_N_LIST_USE: usize = 7;
 #[repr(C)] pub struct RtAux { pub prim_id: *mut u32, pub instance_id: *mut u32, pub flags: *mut u8, pub counters: [u64; RT_N_COUNTERS], pub hit_t: *mut f32 }
 pub enum RtScene {}
 pub enum RtMulti {}
@@ -56,6 +57,8 @@ extern "C" {
     pub fn rt_render(s: *mut RtScene, p: *const RtRenderParams, out_pixels: *mut u8, aux: *mut RtAux) -> c_int;
     pub fn rt_render_device(s: *mut RtScene, p: *const RtRenderParams, d_out: *mut c_void) -> c_int;
     pub fn rt_render_device_noalloc(s: *mut RtScene, p: *const RtRenderParams, d_out: *mut c_void) -> c_int;
+    pub fn rt_last_ray_counts(s: *mut RtScene, counters: *mut u64) -> c_int;
+    pub fn rt_last_list_use(s: *mut RtScene, out: *mut u64) -> c_int;
     pub fn rt_scene_destroy(s: *mut RtScene);
     pub fn rt_multi_create(desc: *const RtSceneDesc, device_ids: *const c_int, n_devices: c_int, out: *mut *mut RtMulti) -> c_int;
     pub fn rt_multi_set_camera(m: *mut RtMulti, screen_to_world: *const f32, width: u32, height: u32) -> c_int;

@@ -322,6 +322,19 @@ void rt_multi_destroy(RtMulti* renderer);
  * overflow is reported once. */
 int rt_last_ray_counts(RtScene* scene, uint64_t counters[RT_N_COUNTERS]);
 
+/* Device memory behind the per-depth work lists of this handle, and how full they were in the frame rendered last
+ * (waits for it to finish): out[RT_LIST_USE_BYTES] = bytes held by the handle's per-frame buffers (colour sums, lists,
+ * walk stacks); RT_LIST_USE_*_SLOTS = entries one recursion depth can hold of each kind of list - rays, walk items ((ray,
+ * instance) pairs for the BVH walk), hit records; RT_LIST_USE_RAYS / _WALK_ITEMS / _HITS = entries the fullest depth of that
+ * frame held.  A handle starts with lists of four rays per pixel and depth; every frame counted by this call, by
+ * rt_last_ray_counts or by rt_render is remembered, and the next time the handle makes buffers for a frame of that size
+ * they are half as long again as the fullest lists seen (buffers made on the first guess are given back then).  Overflows
+ * are handled as before: the frame is reported, the lists double.  No counterpart in the reference, whose recursion
+ * (raytracer.rs:65-135) keeps its rays on the call stack. */
+enum { RT_LIST_USE_BYTES = 0, RT_LIST_USE_RAY_SLOTS, RT_LIST_USE_WALK_SLOTS, RT_LIST_USE_HIT_SLOTS,
+       RT_LIST_USE_RAYS, RT_LIST_USE_WALK_ITEMS, RT_LIST_USE_HITS, RT_N_LIST_USE };
+int rt_last_list_use(RtScene* scene, uint64_t out[RT_N_LIST_USE]);
+
 /* Time of the last rt_render / rt_render_device on this handle between its first and last
  * enqueued command, measured with HIP events on the stream the kernels ran on. */
 int rt_last_render_ms(RtScene* scene, float* out_ms);
@@ -348,7 +361,7 @@ int rt_last_kernel_ms(RtScene* scene, float out_ms[RT_N_LEVEL_KERNELS], uint32_t
 void rt_scene_destroy(RtScene* scene);
 
 /* Test aids.  The first sets how many rays a list of one recursion depth can hold (0 = the default,
- * eight per pixel).  When a list overflows, the kernels raise a flag: rt_render then enlarges the lists
+ * four per pixel, or what the handle has measured).  When a list overflows, the kernels raise a flag: rt_render then enlarges the lists
  * and renders the frame again (the second call reports how often it had to for its last frame);
  * after rt_render_device the overflow is reported by rt_last_ray_counts, and the next frame gets
  * longer lists. */

@@ -28,6 +28,9 @@ RT_FLAG_HIT, RT_FLAG_FRONTSIDE, RT_FLAG_REFLECTION_HIT, RT_FLAG_REFRACTION_HIT, 
 COUNTER_NAMES = ["rays", "primary", "shadow", "reflected", "transmitted", "aabb_tests", "mesh_triangle_tests",
                  "triangle_tests", "sphere_tests", "plane_tests", "instance_transforms", "mesh_hits", "light_shades",
                  "walk_node_visits", "walk_triangle_tests", "walk_heavy_pairs"]
+(RT_LIST_USE_BYTES, RT_LIST_USE_RAY_SLOTS, RT_LIST_USE_WALK_SLOTS, RT_LIST_USE_HIT_SLOTS, RT_LIST_USE_RAYS,
+ RT_LIST_USE_WALK_ITEMS, RT_LIST_USE_HITS, RT_N_LIST_USE) = range(8)
+LIST_USE_NAMES = ["bytes", "ray_slots", "walk_slots", "hit_slots", "rays", "walk_items", "hits"]
 RT_FORMAT_RGB8, RT_FORMAT_RGBA8 = 0, 1
 RT_TILE_DIM = 32
 RT_MAX_VIEWS = 32

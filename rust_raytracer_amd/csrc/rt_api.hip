@@ -74,8 +74,19 @@ struct RtScene {
     // handle launches the kernel at every depth.
     uint32_t slow_seen = 0;
     bool slow_enabled = false;          // rt_setup_slow is launched at every depth
-    uint32_t capacity_shift = 0;        // lists are (default capacity << capacity_shift) rays long
+    uint32_t capacity_shift = 0;        // lists are (what a frame asks for << capacity_shift) entries long
     bool must_grow = false;             // a frame overflowed: the next one needs lists longer than it had
+    // What the frames of this handle have needed, in entries per pixel of the fullest depth, for the three kinds of list
+    // (rays, walk items, hit records) - taken whenever the caller has the lists counted (measure_lists).  Once known,
+    // lists are made half as long again as that instead of the first guess of four rays per pixel.
+    double seen_per_pixel[3] = {0.0, 0.0, 0.0};
+    bool seen_valid = false;
+    uint32_t seen_pixels = 0;           // pixel count of the frame measured last
+    bool trim_pending = false;          // a measurement has come in since the buffers were made
+    uint64_t last_used[3] = {0, 0, 0};  // entries in the fullest depth of the frame measured last
+    size_t frame_bytes = 0;             // device memory held by the per-frame buffers
+    uint32_t last_rows = 0;             // depths of the frame enqueued last whose count rows are valid
+    bool last_noalloc = false;
     uint32_t noalloc_seq_lo = 1, noalloc_seq_hi = 0;     // sequence numbers of the latest run of rt_render_device_noalloc frames
     uint32_t walk_contiguous = 0;       // see DFrame::walk_contiguous
     uint32_t walk_packet_levels = 0;    // see DFrame::walk_packet_levels (RT_WALK_PACKET_LEVELS)
@@ -88,7 +99,7 @@ struct RtScene {
     uint32_t n_views = 1;
     uint32_t width = 0, height = 0;
     // per-frame buffers, reallocated when the key below changes
-    struct FrameKey { uint32_t w = 0, h = 0, shard_count = 0, max_depth = 0, aux = 0, blocks = 0, capacity = 0, debug = 0; } key;
+    struct FrameKey { uint32_t w = 0, h = 0, shard_count = 0, max_depth = 0, aux = 0, blocks = 0, debug = 0; uint64_t rays = 0, fat = 0, hits = 0; } key;
     DFrame f{};
     DFrame last_f{};                    // the frame enqueued last (its statistics are what rt_last_ray_counts reads)
     size_t last_stats_words = 0;
@@ -674,20 +685,31 @@ static uint32_t ceil_div(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1)
 // What a frame's buffers hold besides the pointers in DFrame.
 struct FrameSizes { size_t pixel_clear_bytes = 0, counter_words = 0, stats_words = 0; };
 
-// Lays out the per-frame buffers of DFrame for `n_pixels` local pixels, lists of `capacity` rays per recursion depth cut
+// Entries per recursion depth of the three kinds of list: rays (the child rays made at the depth above), walk items ((ray,
+// instance) pairs for the BVH walk) and hit records (whose shadow rays the next depth traces).
+struct ListCaps { uint64_t rays = 0, fat = 0, hits = 0; };
+
+// The first guess for a handle that has not measured anything: `rays` per depth, half as many walk items and hit records.
+static ListCaps caps_from_rays(uint64_t rays) { ListCaps c; c.rays = rays; c.fat = rays / 2; c.hits = rays / 2; return c; }
+
+// Lays out the per-frame buffers of DFrame for `n_pixels` local pixels, lists of `cap` entries per recursion depth cut
 // into `blocks` producer segments (none shorter than seg_min) plus the shared overflow segment.  Memory comes from
 // `take(bytes, &ptr)`, which returns RT_OK or an error code: hipMalloc for the handle's own buffers, a bump pointer over
 // the static scratch array for rt_render_device_noalloc.
 template <class Take>
-static int carve_frame(uint32_t n_pixels, uint32_t n_lights, uint32_t blocks, uint64_t capacity, uint32_t seg_min, bool aux,
+static int carve_frame(uint32_t n_pixels, uint32_t n_lights, uint32_t blocks, const ListCaps& cap, uint32_t seg_min, bool aux,
                        uint32_t spill_entries, uint32_t spill_lanes, Take&& take, DFrame* out, FrameSizes* sz) {
     DFrame& f = *out;
     memset(&f, 0, sizeof(f));
     f.n_seg = blocks + 1;
     auto seg = [&](uint64_t total) { return std::max<uint32_t>(ceil_div(total, blocks), seg_min); };
-    f.seg_rays = seg(capacity);          f.ovf_rays = (uint32_t)(capacity / 4 + 1024);
-    f.seg_fat = seg(capacity / 2);       f.ovf_fat = (uint32_t)(capacity / 8 + 1024);
-    f.seg_hits = seg(capacity / 2);      f.ovf_hits = (uint32_t)(capacity / 8 + 1024);
+    // (what a block emits varies with what its chunks show - most for the walk items: on the 1080p bunnies frame the fullest
+    // segment holds 3.8 times the mean, 2.3 times for the child rays, 1.2 times for the hit records)
+    f.seg_rays = seg(cap.rays);          f.ovf_rays = (uint32_t)(cap.rays / 8 + 1024);
+    f.seg_fat = seg(cap.fat);            f.ovf_fat = (uint32_t)(cap.fat / 4 + 1024);
+    f.seg_hits = seg(cap.hits);          f.ovf_hits = (uint32_t)(cap.hits / 8 + 1024);
+    f.extra_rays_cap = std::max<uint32_t>(f.seg_rays, 512);
+    f.extra_hits_cap = std::max<uint32_t>(f.seg_hits, 256);
     const size_t ray_slots = (size_t)blocks * f.seg_rays + f.ovf_rays;
     const size_t fat_slots = (size_t)blocks * f.seg_fat + f.ovf_fat;
     const size_t hit_slots = (size_t)blocks * f.seg_hits + f.ovf_hits;
@@ -712,7 +734,8 @@ static int carve_frame(uint32_t n_pixels, uint32_t n_lights, uint32_t blocks, ui
         (rc = get(fat_slots, &f.item_results[0])) || (rc = get(fat_slots, &f.item_results[1])) ||
         (rc = get(4 * fat_slots, &f.fat_items[0])) || (rc = get(4 * fat_slots, &f.fat_items[1])) || (rc = get(ray_slots, &f.slow_rays)) ||
         (rc = get(3 * hit_slots, &f.hits[0])) || (rc = get(3 * hit_slots, &f.hits[1])) ||
-        (rc = get((size_t)(RT_MAX_DEPTH_LIMIT + 2) * RT_HEAVY_CAP, &f.heavy_items)))
+        (rc = get((size_t)(RT_MAX_DEPTH_LIMIT + 2) * RT_HEAVY_CAP, &f.heavy_items)) ||
+        (rc = get((size_t)blocks * (f.extra_rays_cap + f.extra_hits_cap), &f.extras)))
         return rc;
     f.shadow_base = (uint32_t)ray_slots;
     f.n_fat_slots = (uint32_t)fat_slots;
@@ -755,48 +778,95 @@ static uint32_t spill_entries(const RtScene* s) {
     return s->d.stack_entries - s->d.stack_lds + (s->walk_packet_levels ? 32u : 0u);
 }
 
+// Bytes the buffers of such a frame take (the layout run without memory behind it).
+static size_t frame_bytes_for(const RtScene* s, uint32_t n_pixels, const ListCaps& cap, uint32_t seg_min, bool aux) {
+    size_t used = 0;
+    auto take = [&](size_t bytes, void** p) { *p = nullptr; used += (bytes + 255) & ~(size_t)255; return (int)RT_OK; };
+    DFrame f;
+    FrameSizes sz;
+    if (carve_frame(n_pixels, s->d.n_lights, s->list_blocks, cap, seg_min, aux, spill_entries(s), s->traverse_blocks * 256u, take, &f, &sz))
+        return ~(size_t)0;
+    return used;
+}
+
 static int ensure_frame(RtScene* s, const Geometry& g, uint32_t max_depth, bool aux) {
     const uint32_t blocks = s->list_blocks;
-    // rays one depth may hold (its child rays and the shadow rays of the depth above): 4 per pixel to begin with (the 1080p
-    // bunnies frame needs 0.7 at its fullest depth; a frame that needs more has its lists doubled, see note_overflow)
-    uint64_t capacity = s->debug_queue_capacity ? s->debug_queue_capacity : (uint64_t)4 * g.n_pixels;
-    if (const char* env = getenv("RT_QUEUE_CAPACITY")) { long v = atol(env); if (v > 0 && !s->debug_queue_capacity) capacity = (uint64_t)v; }
-    // doubled once per overflow seen, but never beyond 2^30 rays per depth: a frame that needs more keeps overflowing and is
-    // reported as such, the handle stays usable for smaller frames
-    while (s->capacity_shift > 0 && (s->capacity_shift >= 32 || (capacity << s->capacity_shift) > (1ull << 30))) --s->capacity_shift;
-    capacity <<= s->capacity_shift;
+    const bool forced = s->debug_queue_capacity != 0;
+    const uint64_t limit = 1ull << 30;
+    // A block's own segment is never smaller than 1024 entries: with small frames the work is spread unevenly
+    // over the blocks, and whatever does not fit a segment has to go through the shared overflow segment.
+    const uint32_t seg_min = forced ? 1u : 1024u;                            // (tests force overflows with tiny lists)
+    // What the lists of one depth may hold.  A handle that has had its lists counted (measure_lists) gets half as much
+    // again as its fullest depth held per pixel (the 1080p bunnies frame: 0.7 child rays, 0.5 walk items and 0.9 hit
+    // records) - and room for the primary rays, one per pixel, which rt_generate deals out a chunk per wave at a time (a
+    // block's share is up to an eighth above the mean at that size); before that, four rays per pixel - less where that
+    // would not fit the device's free memory.  A frame that needs more has its lists doubled, see note_overflow.
+    ListCaps want = caps_from_rays((uint64_t)4 * g.n_pixels);
+    long env_capacity = 0;
+    if (const char* env = getenv("RT_QUEUE_CAPACITY")) env_capacity = atol(env);
+    if (forced) want = caps_from_rays(s->debug_queue_capacity);
+    else if (env_capacity > 0) want = caps_from_rays((uint64_t)env_capacity);
+    else if (s->seen_valid) {
+        auto half_again = [&](double per_pixel) { return (uint64_t)(1.5 * per_pixel * (double)g.n_pixels) + 4096; };
+        want.rays = std::max(half_again(s->seen_per_pixel[0]), (uint64_t)g.n_pixels + g.n_pixels / 8 + 4096);
+        want.fat = half_again(s->seen_per_pixel[1]);
+        want.hits = half_again(s->seen_per_pixel[2]);
+    } else {
+        size_t free_bytes = 0, total_bytes = 0;
+        if (hipMemGetInfo(&free_bytes, &total_bytes) == hipSuccess) {
+            const size_t room = (free_bytes + s->frame_bytes) / 10 * 8;
+            while (want.rays > g.n_pixels && frame_bytes_for(s, g.n_pixels, want, seg_min, aux) > room) want = caps_from_rays(want.rays / 2);
+        }
+    }
+    auto largest = [](const ListCaps& c) { return std::max(c.rays, std::max(c.fat, c.hits)); };
+    auto shifted = [](ListCaps c, uint32_t by) { c.rays <<= by; c.fat <<= by; c.hits <<= by; return c; };
+    // doubled once per overflow seen, but never beyond 2^30 entries per depth: a frame that needs more keeps overflowing and
+    // is reported as such, the handle stays usable for smaller frames
+    while (s->capacity_shift > 0 && (s->capacity_shift >= 32 || (largest(want) << s->capacity_shift) > limit)) --s->capacity_shift;
+    want = shifted(want, s->capacity_shift);
     if (s->must_grow) {
-        // a frame overflowed the lists it had - which may have been longer than this size asks for (see `fits`)
-        while (!s->debug_queue_capacity && capacity <= s->key.capacity && capacity < (1ull << 30)) { capacity <<= 1; ++s->capacity_shift; }
+        // a frame overflowed the lists it had - which may have been longer than this size asks for (see `fits`); which of
+        // its lists it was is not known, so every one gets longer than it was
+        while (!forced && (want.rays <= s->key.rays || want.fat <= s->key.fat || want.hits <= s->key.hits) && largest(want) < limit) {
+            want = shifted(want, 1);
+            ++s->capacity_shift;
+        }
         s->must_grow = false;
     }
-    if (capacity < 4096) capacity = 4096;
-    if (capacity > (1ull << 30)) return fail(RT_ERR_OUT_OF_RANGE, "a frame needs more than 2^30 rays per depth");
+    if (!forced) { want.rays = std::max<uint64_t>(want.rays, 4096); want.fat = std::max<uint64_t>(want.fat, 4096); want.hits = std::max<uint64_t>(want.hits, 4096); }
+    if (largest(want) > limit) return fail(RT_ERR_OUT_OF_RANGE, "a frame needs more than 2^30 list entries per depth");
     RtScene::FrameKey k;
     k.w = g.n_pixels; k.h = s->d.n_lights; k.shard_count = g.shard_count; k.max_depth = max_depth; k.aux = aux; k.blocks = blocks;
-    k.capacity = (uint32_t)capacity;
-    k.debug = s->debug_queue_capacity != 0;
+    k.rays = want.rays; k.fat = want.fat; k.hits = want.hits;
+    k.debug = forced;
     // Buffers made for a larger frame serve a smaller one (fewer views, say) as they are: the lists are only longer
     // than needed, and the per-pixel arrays are addressed through the current pixel count below.  With a forced list
     // capacity (tests) the match has to be exact, or a test's short lists would silently be the previous long ones.
-    const bool fits = s->debug_queue_capacity || s->key.debug ? (k.w == s->key.w && k.capacity == s->key.capacity)
-                                                              : (k.w <= s->key.w && k.capacity <= s->key.capacity);
+    bool fits = forced || s->key.debug ? (k.w == s->key.w && k.rays == s->key.rays && k.fat == s->key.fat && k.hits == s->key.hits)
+                                       : (k.w <= s->key.w && k.rays <= s->key.rays && k.fat <= s->key.fat && k.hits <= s->key.hits);
+    // Buffers made on the first guess are given back once a frame of this very size has been counted and needs less
+    // than 70 % of them (a handle that alternates between frame sizes keeps the larger buffers).
+    if (s->trim_pending) {
+        if (fits && !forced && !s->key.debug && k.w == s->key.w && s->seen_pixels == k.w && !s->frame_allocs.empty() &&
+            frame_bytes_for(s, g.n_pixels, want, seg_min, s->key.aux) < s->frame_bytes / 10 * 7)
+            fits = false;
+        s->trim_pending = false;
+    }
     bool same = fits && k.h == s->key.h && k.blocks == s->key.blocks && (s->key.aux || !aux) && !s->frame_allocs.empty();
     if (!same) {
         HIP_TRY(hipDeviceSynchronize());
         for (void* p : s->frame_allocs) (void)hipFree(p);
         s->frame_allocs.clear();
+        s->frame_bytes = 0;
         s->key = RtScene::FrameKey();
-        // A block's own segment is never smaller than 1024 entries: with small frames the work is spread unevenly
-        // over the blocks, and whatever does not fit a segment has to go through the shared overflow segment.
-        const uint32_t seg_min = s->debug_queue_capacity ? 1u : 1024u;       // (tests force overflows with tiny lists)
         FrameSizes sz;
         auto take = [&](size_t bytes, void** p) {
             HIP_TRY(hipMalloc(p, bytes));
             s->frame_allocs.push_back(*p);
+            s->frame_bytes += bytes;
             return (int)RT_OK;
         };
-        int rc = carve_frame(g.n_pixels, s->d.n_lights, blocks, capacity, seg_min, aux, spill_entries(s),
+        int rc = carve_frame(g.n_pixels, s->d.n_lights, blocks, want, seg_min, aux, spill_entries(s),
                              s->traverse_blocks * 256u, take, &s->f, &sz);
         if (rc) return rc;
         s->stats_words = sz.stats_words;
@@ -883,8 +953,8 @@ static int enqueue_frame(RtScene* s, const RtRenderParams* p, bool sharded, bool
             used = at + bytes;
             return (int)RT_OK;
         };
-        const uint64_t capacity = std::max<uint64_t>((uint64_t)8 * g.n_pixels, 4096);
-        if ((rc = carve_frame(g.n_pixels, s->d.n_lights, blocks, capacity, 64u, false, spill_entries(s),
+        const ListCaps cap = caps_from_rays(std::max<uint64_t>((uint64_t)8 * g.n_pixels, 4096));
+        if ((rc = carve_frame(g.n_pixels, s->d.n_lights, blocks, cap, 64u, false, spill_entries(s),
                               s->traverse_blocks * 256u, take, &f, &sz))) return rc;
         if (used > RT_NOALLOC_SCRATCH_BYTES)
             return fail(RT_ERR_OUT_OF_RANGE,
@@ -938,6 +1008,8 @@ static int enqueue_frame(RtScene* s, const RtRenderParams* p, bool sharded, bool
     s->last_f = f;
     s->last_fused = f.fuse_setup != 0;
     s->last_stats_words = sz.stats_words;
+    s->last_rows = last + 2;
+    s->last_noalloc = noalloc;
     return RT_OK;
 }
 
@@ -966,6 +1038,8 @@ extern "C" int rt_noalloc_scratch_bytes(uint64_t* out_bytes) {
     *out_bytes = RT_NOALLOC_SCRATCH_BYTES;
     return RT_OK;
 }
+
+static int measure_lists(RtScene* s);
 
 extern "C" int rt_render(RtScene* s, const RtRenderParams* p, uint8_t* out_pixels, RtAux* aux) {
     if (!s || !p || !out_pixels) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: null argument");
@@ -1018,12 +1092,11 @@ extern "C" int rt_render(RtScene* s, const RtRenderParams* p, uint8_t* out_pixel
         ++s->regrown;
         if (s->regrown > 16) return fail(RT_ERR_OUT_OF_RANGE, "the ray lists keep overflowing");
     }
-    int rc = RT_OK;
     if (aux) {
         memset(aux->counters, 0, sizeof(aux->counters));
-        rc = rt_last_ray_counts(s, aux->counters);
+        return rt_last_ray_counts(s, aux->counters);
     }
-    return rc;
+    return measure_lists(s);
 }
 
 extern "C" int rt_assemble_shards(RtScene* s, const RtRenderParams* p, const void* d_gathered, void* d_frame) {
@@ -1052,6 +1125,69 @@ static int sum_wave_stats(RtScene* s, uint64_t sums[8]) {
     return RT_OK;
 }
 
+// Counts what the lists of the frame enqueued last held at their fullest depth (the stream has been waited for) and, if the
+// frame was complete, remembers it per pixel: the next buffers this handle makes are sized by it (ensure_frame).
+static int measure_lists(RtScene* s) {
+    if (s->last_noalloc || s->last_rows == 0) return RT_OK;               // lists in the static scratch are not the handle's to size
+    const DFrame& f = s->last_f;
+    const size_t row = f.n_seg, words = (size_t)RT_COUNT_ROWS * s->last_rows * row;
+    std::vector<unsigned int> host(words);
+    HIP_TRY(hipMemcpy(host.data(), f.counts, words * sizeof(unsigned int), hipMemcpyDeviceToHost));
+    if (getenv("RT_DEBUG_LISTS")) {
+        // per depth and list: entries in all, the fullest producer segment against its capacity, the shared overflow segment
+        const char* names[RT_COUNT_ROWS] = {"rays", "hits", "walk", "slow"};
+        const uint32_t seg_cap[RT_COUNT_ROWS] = {f.seg_rays, f.seg_hits, f.seg_fat, f.seg_rays};
+        const uint32_t ovf_cap[RT_COUNT_ROWS] = {f.ovf_rays, f.ovf_hits, f.ovf_fat, f.ovf_rays};
+        for (uint32_t d = 0; d < s->last_rows; ++d)
+            for (int k = 0; k < RT_COUNT_ROWS; ++k) {
+                const unsigned int* c = &host[((size_t)RT_COUNT_ROWS * d + k) * row];
+                uint64_t sum = 0; unsigned int fullest = 0;
+                for (size_t i = 0; i + 1 < row; ++i) { sum += c[i]; fullest = std::max(fullest, c[i]); }
+                if (sum + c[row - 1]) fprintf(stderr, "[lists] frame %u depth %u %s: %llu entries, fullest segment %u of %u, overflow segment %u of %u\n",
+                                              s->frame_seq, d, names[k], (unsigned long long)(sum + c[row - 1]), fullest, seg_cap[k], c[row - 1], ovf_cap[k]);
+            }
+    }
+    const int rows_of[3] = {RT_ROW_RAYS, RT_ROW_FAT, RT_ROW_HITS};
+    uint64_t child_rays = 0;                                               // the fullest ray list below the primary rays'
+    for (int k = 0; k < 3; ++k) {
+        uint64_t most = 0;
+        for (uint32_t d = 0; d < s->last_rows; ++d) {
+            uint64_t sum = 0;
+            const unsigned int* c = &host[((size_t)RT_COUNT_ROWS * d + rows_of[k]) * row];
+            for (size_t i = 0; i < row; ++i) sum += c[i];
+            most = std::max(most, sum);
+            if (k == 0 && d > 0) child_rays = std::max(child_rays, sum);
+        }
+        s->last_used[k] = most;
+    }
+    if (s->h_overflow[0] == s->frame_seq || s->debug_queue_capacity) return RT_OK;      // clipped counts say nothing
+    const uint64_t sized_by[3] = {child_rays, s->last_used[1], s->last_used[2]};
+    for (int k = 0; k < 3; ++k) s->seen_per_pixel[k] = std::max(s->seen_per_pixel[k], (double)sized_by[k] / (double)f.n_pixels);
+    s->seen_valid = true;
+    s->seen_pixels = f.n_pixels;
+    s->trim_pending = true;
+    if (!s->must_grow) s->capacity_shift = 0;                               // the measured need replaces the doublings
+    return RT_OK;
+}
+
+extern "C" int rt_last_list_use(RtScene* s, uint64_t out[RT_N_LIST_USE]) {
+    if (!s || !out) return fail(RT_ERR_INVALID_ARGUMENT, "rt_last_list_use: null argument");
+    if (!s->timed) return fail(RT_ERR_INVALID_ARGUMENT, "nothing has been rendered on this handle yet");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->last_stream));
+    note_overflow(s);
+    int rc = measure_lists(s);
+    if (rc) return rc;
+    out[RT_LIST_USE_BYTES] = s->frame_bytes;
+    out[RT_LIST_USE_RAY_SLOTS] = s->key.rays;
+    out[RT_LIST_USE_WALK_SLOTS] = s->key.fat;
+    out[RT_LIST_USE_HIT_SLOTS] = s->key.hits;
+    out[RT_LIST_USE_RAYS] = s->last_used[0];
+    out[RT_LIST_USE_WALK_ITEMS] = s->last_used[1];
+    out[RT_LIST_USE_HITS] = s->last_used[2];
+    return RT_OK;
+}
+
 extern "C" int rt_last_ray_counts(RtScene* s, uint64_t counters[RT_N_COUNTERS]) {
     if (!s || !counters) return fail(RT_ERR_INVALID_ARGUMENT, "rt_last_ray_counts: null argument");
     if (!s->timed) return fail(RT_ERR_INVALID_ARGUMENT, "nothing has been rendered on this handle yet");
@@ -1067,6 +1203,7 @@ extern "C" int rt_last_ray_counts(RtScene* s, uint64_t counters[RT_N_COUNTERS]) 
     uint64_t sums[8];
     int rc = sum_wave_stats(s, sums);
     if (rc) return rc;
+    if ((rc = measure_lists(s))) return rc;
     for (int k = 0; k < RT_N_COUNTERS; ++k) counters[k] = 0;
     for (int k = 0; k < 5; ++k) counters[k] = sums[k];
     counters[RT_CTR_WALK_NODE_VISITS] = sums[5];

@@ -22,7 +22,7 @@ struct float4 { float x, y, z, w; };
 
 #define RT_STACK_LDS_MAX 12         // traversal stack entries per lane kept in LDS (four blocks of the BVH walk per compute unit)
 #define RT_MAX_DEPTH_LIMIT 63      // depth is carried in 6 bits of a ray record
-#define RT_MAX_PIXELS_PER_SHARD (1u << 25)
+#define RT_MAX_PIXELS_PER_SHARD (1u << 28)
 #define RT_META_RAY_LIMIT 0x7FFFFFFFull   // ray slots are 31-bit numbers
 
 struct DLight {
@@ -194,6 +194,10 @@ struct DFrame {
     float4* item_results[2];         // per walk item: local t, u, v, bits triangle slot
     unsigned int* slow_rays;         // ray slots rt_setup left to rt_setup_slow, segmented like the ray lists
     unsigned int* slow_flags;        // [RT_MAX_DEPTH_LIMIT + 2] set when a depth has such rays
+    // rt_shade setting up the next depth itself: the slots a block took from the shared overflow segments, which are not in
+    // its own segments - per block extra_rays_cap slots of rays, then extra_hits_cap of hit records
+    uint32_t* extras;
+    uint32_t extra_rays_cap, extra_hits_cap;
     uint2* spill;                    // traversal stack entries beyond DScene::stack_lds: entry e of walking lane g at [e * spill_lanes + g]
     uint32_t spill_lanes;            // lanes of the BVH walk's grid
     uint32_t walk_contiguous;        // the walk hands out runs of neighbouring pairs instead of interleaving them: 0 never, 1 always, 2 in launches with several chunks per wave

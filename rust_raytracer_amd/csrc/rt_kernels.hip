@@ -303,7 +303,13 @@ __device__ __forceinline__ void add_channel(const DFrame& F, uint32_t pixel, int
     if (v == 0.0f) return;
     if (fabsf(v) < RT_FIXED_LIMIT) {
         long long q = __double2ll_rn((double)v * RT_FIXED_ONE);
+#if defined(RT_PROBE_PLAIN_COLOUR_STORES)
+        F.acc[(size_t)c * F.n_pixels + pixel] = q;                  // timing probe only: wrong pictures
+#elif defined(RT_PROBE_NO_COLOUR)
+        if (q == 0x7FFFFFFFFFFFFFFFll) F.acc[(size_t)c * F.n_pixels + pixel] = q;      // timing probe only: (never true)
+#else
         atomicAdd(reinterpret_cast<unsigned long long*>(F.acc + (size_t)c * F.n_pixels + pixel), (unsigned long long)q);
+#endif
     } else if (finite1(v)) {
         atomicAdd(F.acc_big + (size_t)c * F.n_pixels + pixel, (double)v);
         atomicOr(F.poison + pixel, RT_POISON_BIG);
@@ -320,9 +326,8 @@ __device__ __forceinline__ void add_color(const DFrame& F, uint32_t pixel, V3 c)
 }
 
 // ---- ray records -------------------------------------------------------------------------------
-#define RT_META_PIXEL_MASK 0x01FFFFFFu
-#define RT_META_KIND_SHIFT 25            // 0 = primary / reflected, 1 = transmitted
-#define RT_META_DEPTH_SHIFT 26
+#define RT_META_PIXEL_MASK 0x0FFFFFFFu     // RT_MAX_PIXELS_PER_SHARD - 1
+#define RT_META_KIND_SHIFT 28            // 0 = primary / reflected, 1 = transmitted
 
 #define RT_RAY_SHADOW_BIT 0x80000000u    // = RT_RAY_SHADOW, see the work lists below
 struct RayRec { Ray ray; float throughput; uint32_t meta; };
@@ -1994,10 +1999,10 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_traverse_packet(const DSc
 // of the previous depth, now that their shadow rays have been traced.  Block-wide (it builds a prefix table).
 // ======================================================================================================
 // rt_shade with setup_next: a slot in a shared overflow segment is not in the block's own segment, so the block keeps a
-// list of those it took (few, if any).  A block that takes more than the list holds spoils the frame, which is then redone
-// with longer lists, like any frame whose lists were too short.
-#define RT_LOCAL_EXTRA_RAYS 512     // (what the four waves of a block can emit from one chunk of rays each)
-#define RT_LOCAL_EXTRA_HITS 256
+// list of those it took in device memory (DFrame::extras; as long as its own segments, since what a block emits varies
+// with what its chunks show: on the 1080p bunnies frame the fullest segment of child rays holds 2.3 times the mean).  A
+// block that takes more than the list holds spoils the frame, which is then redone with longer lists, like any frame
+// whose lists were too short.
 // Its entry stays in the list, though, and nobody sets it up: its `keys_per_slot` keys (the key of a ray; the keys of the
 // shadow rays of a hit record) are written here, so that the next depth finds well-formed ones.
 __device__ __forceinline__ void note_extra(const DFrame& F, uint32_t slot, uint32_t seg_cap, uint32_t* list, uint32_t list_len, uint32_t* n,
@@ -2072,11 +2077,11 @@ __global__ void __launch_bounds__(RT_SHADE_THREADS) rt_shade(const DScene S, con
 #endif
     const LevelLists L = level_lists(F, level);
     extern __shared__ uint32_t lds[];
-    // With setup_next the block first keeps the slots it takes from the shared overflow segments; what setup_rays needs
+    // With setup_next the block keeps the slots it takes from the shared overflow segments; what setup_rays needs
     // later (staged primitives, range-tree stacks, rings) lies over the prefix table, which is done with by then.
-    uint32_t* extra_rays = lds;
-    uint32_t* extra_hits = extra_rays + RT_LOCAL_EXTRA_RAYS;
-    uint32_t* pre = setup_next ? extra_hits + RT_LOCAL_EXTRA_HITS : lds;
+    uint32_t* extra_rays = F.extras + (size_t)blockIdx.x * (F.extra_rays_cap + F.extra_hits_cap);
+    uint32_t* extra_hits = extra_rays + F.extra_rays_cap;
+    uint32_t* pre = lds;
     uint32_t* scratch = pre + F.n_seg + 1;
     __shared__ uint32_t out_rays, out_hits, n_extra_rays, n_extra_hits, fat_n, slow_n;
     if (threadIdx.x == 0) { out_rays = 0; out_hits = 0; n_extra_rays = 0; n_extra_hits = 0; fat_n = 0; slow_n = 0; }
@@ -2209,7 +2214,7 @@ __global__ void __launch_bounds__(RT_SHADE_THREADS) rt_shade(const DScene S, con
 
         // ---- append: hit record, its shadow rays (one per light, raytracer.rs:77-79), child rays ----------
         const uint32_t hit_slot = append_slot(emit_hit, &out_hits, F.seg_hits, F.n_seg, L.next_hit_counts, F.ovf_hits, F.overflow, F.overflow_seq, lane);
-        if (setup_next) note_extra(F, hit_slot, F.seg_hits, extra_hits, RT_LOCAL_EXTRA_HITS, &n_extra_hits, next_best + F.shadow_base, S.n_lights);
+        if (setup_next) note_extra(F, hit_slot, F.seg_hits, extra_hits, F.extra_hits_cap, &n_extra_hits, next_best + F.shadow_base, S.n_lights);
         if (hit_slot != RT_REF_NONE) {
             float4* H = F.hits[p] + 3 * (size_t)hit_slot;
             H[0] = make_float4(hit.position.x, hit.position.y, hit.position.z, __uint_as_float(hit.material));
@@ -2220,12 +2225,12 @@ __global__ void __launch_bounds__(RT_SHADE_THREADS) rt_shade(const DScene S, con
         if (hit_slot != RT_REF_NONE) n_shadow += S.n_lights;
         {
             const uint32_t slot = append_slot(emit_r, &out_rays, F.seg_rays, F.n_seg, L.next_ray_counts, F.ovf_rays, F.overflow, F.overflow_seq, lane);
-            if (setup_next) note_extra(F, slot, F.seg_rays, extra_rays, RT_LOCAL_EXTRA_RAYS, &n_extra_rays, next_best, 1);
+            if (setup_next) note_extra(F, slot, F.seg_rays, extra_rays, F.extra_rays_cap, &n_extra_rays, next_best, 1);
             if (slot != RT_REF_NONE) store_rec(rays_out, slot, rec_r);
         }
         {
             const uint32_t slot = append_slot(emit_t, &out_rays, F.seg_rays, F.n_seg, L.next_ray_counts, F.ovf_rays, F.overflow, F.overflow_seq, lane);
-            if (setup_next) note_extra(F, slot, F.seg_rays, extra_rays, RT_LOCAL_EXTRA_RAYS, &n_extra_rays, next_best, 1);
+            if (setup_next) note_extra(F, slot, F.seg_rays, extra_rays, F.extra_rays_cap, &n_extra_rays, next_best, 1);
             if (slot != RT_REF_NONE) store_rec(rays_out, slot, rec_t);
         }
     }
@@ -2268,8 +2273,8 @@ __global__ void __launch_bounds__(RT_SHADE_THREADS) rt_shade(const DScene S, con
         in.own_rays = out_rays < F.seg_rays ? out_rays : F.seg_rays;
         in.own_hits = out_hits < F.seg_hits ? out_hits : F.seg_hits;
         in.extra_rays = extra_rays; in.extra_hits = extra_hits;
-        in.n_rays = in.own_rays + (n_extra_rays < RT_LOCAL_EXTRA_RAYS ? n_extra_rays : RT_LOCAL_EXTRA_RAYS);
-        in.n_hits = in.own_hits + (n_extra_hits < RT_LOCAL_EXTRA_HITS ? n_extra_hits : RT_LOCAL_EXTRA_HITS);
+        in.n_rays = in.own_rays + (n_extra_rays < F.extra_rays_cap ? n_extra_rays : F.extra_rays_cap);
+        in.n_hits = in.own_hits + (n_extra_hits < F.extra_hits_cap ? n_extra_hits : F.extra_hits_cap);
         uint32_t* stage = pre;                                        // every wave has left phong_pass (barrier above)
         stage_analytic(S, stage);
         setup_rays<true>(S, F, level + 1, in, stage, &fat_n, &slow_n);
@@ -2416,7 +2421,7 @@ extern "C" hipError_t rt_launch_level(const DScene* S, const DFrame* F, uint32_t
 #endif
     if (marks) (void)hipEventRecord(marks[2], stream);
     const uint32_t setup_next = (F->fuse_setup && level < last) ? 1u : 0u;
-    const size_t shade_lds = setup_next ? (RT_LOCAL_EXTRA_RAYS + RT_LOCAL_EXTRA_HITS) * sizeof(uint32_t) + std::max(lds, setup_words * sizeof(uint32_t)) : lds;
+    const size_t shade_lds = setup_next ? std::max(lds, setup_words * sizeof(uint32_t)) : lds;
     hipLaunchKernelGGL(rt_shade, dim3(blocks), dim3(RT_SHADE_THREADS), shade_lds, stream, *S, *F, level, setup_next);
     if (marks) (void)hipEventRecord(marks[3], stream);
     return hipGetLastError();

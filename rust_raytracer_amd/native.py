@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "librt_hip.so")
 # every function include/rt_hip.h declares
 EXPORTS = ["rt_scene_create", "rt_scene_set_camera", "rt_scene_set_views", "rt_render", "rt_render_device", "rt_render_device_noalloc",
            "rt_noalloc_scratch_bytes", "rt_shard_bytes",
-           "rt_assemble_shards", "rt_last_ray_counts", "rt_last_render_ms", "rt_last_trace_ms", "rt_set_kernel_timing",
+           "rt_assemble_shards", "rt_last_ray_counts", "rt_last_list_use", "rt_last_render_ms", "rt_last_trace_ms", "rt_set_kernel_timing",
            "rt_last_kernel_ms", "rt_scene_destroy",
            "rt_debug_set_queue_capacity", "rt_debug_last_regrown", "rt_last_error",
            "rt_multi_create", "rt_multi_set_camera", "rt_multi_set_views", "rt_multi_render", "rt_multi_render_views", "rt_multi_last_ray_counts",
@@ -77,6 +77,7 @@ def lib():
         L.rt_shard_bytes.argtypes = [vp, C.POINTER(abi.RtRenderParams), C.POINTER(C.c_uint64)]
         L.rt_assemble_shards.argtypes = [vp, C.POINTER(abi.RtRenderParams), vp, vp]
         L.rt_last_ray_counts.argtypes = [vp, C.POINTER(C.c_uint64)]
+        L.rt_last_list_use.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.rt_last_render_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.rt_last_trace_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.rt_set_kernel_timing.argtypes = [vp, C.c_int]
@@ -203,6 +204,13 @@ class DeviceScene:
         c = (C.c_uint64 * abi.RT_N_COUNTERS)()
         check(lib().rt_last_ray_counts(self._h, c))
         return np.array(c, dtype=np.uint64)
+
+    def last_list_use(self) -> dict:
+        """rt_last_list_use: bytes held by the handle's per-frame buffers, entries per depth its lists can hold and entries
+        the fullest depth of the last frame held (counting a frame also lets the handle size its next buffers by it)."""
+        u = (C.c_uint64 * abi.RT_N_LIST_USE)()
+        check(lib().rt_last_list_use(self._h, u))
+        return {name: int(u[k]) for k, name in enumerate(abi.LIST_USE_NAMES)}
 
     def last_render_ms(self) -> float:
         ms = C.c_float()

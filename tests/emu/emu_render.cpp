@@ -83,6 +83,8 @@ int main(int argc, char** argv) {
         //   views:<n>   n views of the same camera in one pass (rt_scene_set_views); the first is written, all must be equal
         //   noalloc     rt_render_device_noalloc
         //   depthmap    rt_render in depth-map mode
+        //   trim        rt_render twice: the second frame's lists are sized by what the first one held (rt_last_list_use) and
+        //               must take less memory and give the same picture
         const char* mode = getenv("EMU_MODE");
         int rc = RT_OK;
         bool with_aux = false;
@@ -113,6 +115,22 @@ int main(int argc, char** argv) {
             rc = rt_render_device_noalloc(scene, &p, rgb.data());
             uint64_t counters[RT_N_COUNTERS];
             if (rc == RT_OK) rc = rt_last_ray_counts(scene, counters);
+        } else if (mode && !strcmp(mode, "trim")) {
+            std::vector<uint8_t> first(n * 3);
+            uint64_t before[RT_N_LIST_USE], after[RT_N_LIST_USE];
+            rc = rt_render(scene, &p, first.data(), nullptr);
+            if (rc == RT_OK) rc = rt_last_list_use(scene, before);
+            if (rc == RT_OK) rc = rt_render(scene, &p, rgb.data(), nullptr);
+            if (rc == RT_OK) rc = rt_last_list_use(scene, after);
+            if (rc == RT_OK) {
+                printf("%s: lists %llu -> %llu bytes, ray slots %llu -> %llu for %llu rays\n", path, (unsigned long long)before[RT_LIST_USE_BYTES],
+                       (unsigned long long)after[RT_LIST_USE_BYTES], (unsigned long long)before[RT_LIST_USE_RAY_SLOTS],
+                       (unsigned long long)after[RT_LIST_USE_RAY_SLOTS], (unsigned long long)after[RT_LIST_USE_RAYS]);
+                const bool smaller = after[RT_LIST_USE_BYTES] * 10 < before[RT_LIST_USE_BYTES] * 7 && after[RT_LIST_USE_RAY_SLOTS] >= after[RT_LIST_USE_RAYS] &&
+                                     after[RT_LIST_USE_WALK_SLOTS] >= after[RT_LIST_USE_WALK_ITEMS] && after[RT_LIST_USE_HIT_SLOTS] >= after[RT_LIST_USE_HITS];
+                if (!smaller) { fprintf(stderr, "%s: the second frame's buffers are not smaller, or shorter than what it held\n", path); rc = -100; }
+                else if (memcmp(first.data(), rgb.data(), n * 3)) { fprintf(stderr, "%s: the second frame differs from the first\n", path); rc = -100; }
+            }
         } else if (mode && !strcmp(mode, "depthmap")) {
             p.mode = RT_MODE_DEPTH_MAP;
             rc = rt_render(scene, &p, rgb.data(), nullptr);
@@ -120,7 +138,7 @@ int main(int argc, char** argv) {
             with_aux = true;
             rc = rt_render(scene, &p, rgb.data(), &aux);
         }
-        if (rc != RT_OK) { fprintf(stderr, "%s: render: %s\n", path, rc == -100 ? "views differ" : rt_last_error()); ++failures; }
+        if (rc != RT_OK) { fprintf(stderr, "%s: render: %s\n", path, rc == -100 ? "frames differ (see above)" : rt_last_error()); ++failures; }
         else {
             dump(out + ".rgb", rgb.data(), rgb.size());
             if (with_aux) {

@@ -206,6 +206,7 @@ hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned int) { return hipSuccess; }
 hipError_t hipDeviceSynchronize() { return hipSuccess; }
+hipError_t hipMemGetInfo(size_t* free_bytes, size_t* total_bytes) { *free_bytes = *total_bytes = (size_t)4 << 30; return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t* e) { *e = new emuEvent(); return hipSuccess; }
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned int) { *e = new emuEvent(); return hipSuccess; }
 hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }

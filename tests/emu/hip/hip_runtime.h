@@ -137,6 +137,7 @@ hipError_t hipStreamDestroy(hipStream_t s);
 hipError_t hipStreamSynchronize(hipStream_t s);
 hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned int flags);
 hipError_t hipDeviceSynchronize();
+hipError_t hipMemGetInfo(size_t* free_bytes, size_t* total_bytes);
 hipError_t hipEventCreate(hipEvent_t* e);
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned int flags);
 hipError_t hipEventDestroy(hipEvent_t e);

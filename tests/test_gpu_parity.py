@@ -481,6 +481,107 @@ def test_overflow_of_a_device_frame_is_reported_once(scenes_dir, model_dir):
         dev.close()
 
 
+def test_lists_are_sized_by_what_the_handle_has_seen(scenes_dir, model_dir):
+    """A handle's first frame of a size gets lists of four rays per pixel and depth (1.2 KB of device memory per pixel);
+    once a frame has been counted the next one gets lists half as long again as the fullest depth held: 1.0 GiB for the
+    1080p headline frame, the same bytes out, no overflow.  A camera close to a glass sphere (two child rays per hit) then
+    needs more than was seen: the frame is reported, the next one grows, and the picture ends up the oracle's."""
+    import torch
+    s = load(scenes_dir, model_dir, "reflective_bunnies", 1920, 1080)
+    m, w, h = s.camera()
+    dev = native.DeviceScene(s.desc(), 0)
+    try:
+        dev.set_camera(m, w, h)
+        out = torch.zeros(h * w * 3, dtype=torch.uint8, device="cuda")
+        dev.render_device(out.data_ptr())
+        first = dev.last_list_use()
+        first_picture = out.cpu().numpy().copy()
+        assert first["ray_slots"] == 4 * first_picture.size // 3 or first["ray_slots"] == 4 * ((w + 31) // 32) * ((h + 31) // 32) * 1024
+        assert first["rays"] >= w * h and first["walk_items"] > 0 and first["hits"] > 0
+        dev.render_device(out.data_ptr())
+        counts = dev.last_ray_counts()                                   # raises if a list overflowed
+        second = dev.last_list_use()
+        assert second["bytes"] < 1100 << 20 and second["bytes"] * 2 < first["bytes"], (first, second)
+        for slots, used in (("ray_slots", "rays"), ("walk_slots", "walk_items"), ("hit_slots", "hits")):
+            assert second[used] == first[used] and second[used] < second[slots] <= 2 * second[used] + 8192, (slots, first, second)
+        assert np.array_equal(out.cpu().numpy(), first_picture)
+        dev.render_device(out.data_ptr())                                # and the buffers stay as they are now
+        assert dev.last_list_use()["bytes"] == second["bytes"]
+        # a pose that makes more rays per pixel than the handle has seen
+        host = native.HostScene.load(os.path.join(scenes_dir, "reflective_bunnies.json"), model_dir)
+        try:
+            host.resize_screen(w, h)
+            host.set_camera_pose((3.0, -1.0, -2.8), (0.0, 0.0, 0.0))
+            m2, _, _ = host.camera()
+        finally:
+            host.close()
+        m2 = np.asarray(m2, dtype=np.float32).reshape(16)
+        s.set_camera_matrix(m2, w, h)
+        want = s.render()
+        dev.set_camera(m2, w, h)
+        for attempt in range(6):
+            dev.render_device(out.data_ptr())
+            try:
+                got_counts = dev.last_ray_counts()
+                break
+            except native.RtError as e:
+                assert e.code == abi.RT_ERR_OUT_OF_RANGE
+        else:
+            raise AssertionError("the lists never grew enough")
+        assert got_counts[:5].tolist() == [int(x) for x in want["counters"][:5]]
+        diff = np.abs(out.cpu().numpy().reshape(h, w, 3).astype(int) - want["rgb"].astype(int)).max(axis=2)
+        assert (diff <= 1).mean() >= 0.999
+        assert counts[0] > w * h
+    finally:
+        dev.close()
+
+
+def test_five_4k_views_in_one_pass(scenes_dir, model_dir):
+    """Five 3840x2160 views are 41 M pixels in one pass - more than the 2^25 a ray's pixel field once held (now 2^28).  Every
+    view's bytes equal the frame rendered on its own."""
+    import torch
+    from rust_raytracer_amd import synthetic
+    w, h = 3840, 2160
+    host = native.HostScene.load(os.path.join(scenes_dir, "reflective_bunnies.json"), model_dir)
+    host.resize_screen(w, h)
+    mats = []
+    for position, orientation in synthetic.orbit_poses(5, centre=(0.0, 0.0, -6.0)):
+        host.set_camera_pose(position, orientation)
+        mats.append(np.asarray(host.camera()[0], dtype=np.float32).reshape(16))
+    dev = native.DeviceScene(host.desc(), 0)
+    single = native.DeviceScene(host.desc(), 0)
+    try:
+        together = torch.zeros(5 * h * w * 3, dtype=torch.uint8, device="cuda")
+        alone = torch.zeros(h * w * 3, dtype=torch.uint8, device="cuda")
+        dev.set_views(np.stack(mats), w, h)
+        for attempt in range(4):
+            dev.render_device(together.data_ptr())
+            try:
+                total = dev.last_ray_counts()
+                break
+            except native.RtError:
+                if attempt == 3:
+                    raise
+        got = together.cpu().numpy().reshape(5, h, w, 3)
+        rays = 0
+        for v in range(5):
+            single.set_camera(mats[v], w, h)
+            for attempt in range(4):
+                single.render_device(alone.data_ptr())
+                try:
+                    rays += int(single.last_ray_counts()[0])
+                    break
+                except native.RtError:
+                    if attempt == 3:
+                        raise
+            assert np.array_equal(got[v], alone.cpu().numpy().reshape(h, w, 3)), v
+        assert int(total[0]) == rays
+    finally:
+        dev.close()
+        single.close()
+        host.close()
+
+
 def test_stray_rays_switch_the_exact_path_on(scenes_dir, model_dir):
     """The kernel that traces rays with non-finite components in the reference's own order is left out of the launch
     sequence until a frame turns out to hold such rays (here: a camera matrix with a NaN in it, so that every primary

@@ -194,3 +194,16 @@ def test_other_entry_points(emu_render, scenes_dir, model_dir, tmp_path):
     for mode in ("shards:3", "views:2", "noalloc"):
         assert np.array_equal(outputs[mode], outputs["plain"]), mode
     assert outputs["depthmap"].any() and not np.array_equal(outputs["depthmap"], outputs["plain"])
+
+
+def test_lists_sized_by_the_frame_before(emu_render, scenes_dir, model_dir, tmp_path):
+    """A handle's first frame gets lists of four rays per pixel and depth; once a frame has been counted (rt_last_list_use,
+    rt_last_ray_counts, rt_render) the next one of that size gets buffers half as long again as the fullest lists seen:
+    less than 70 % of the memory, the same picture, and no list shorter than what it held (checked in emu_render)."""
+    path = str(tmp_path / "scene.json")
+    with open(path, "w") as f:
+        f.write(small(scenes_dir, "reflective_bunnies", 160, 100))
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", EMU_MODE="trim")
+    r = subprocess.run([emu_render, model_dir, "3", path, str(tmp_path / "trim")], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "lists " in r.stdout and "rendered 1 time(s)" in r.stdout, r.stdout      # and the shorter lists did not overflow
