@@ -418,6 +418,24 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device_id, RtScene**
     for (uint32_t i = 0; i < desc->n_materials; ++i)
         if (materials[i].material_type > RT_MATERIAL_REFLECT_AND_REFRACT)
             return fail(RT_ERR_INVALID_ARGUMENT, "material %u: unknown material_type %u", i, materials[i].material_type);
+    // what a shadow verdict can change in radiance() per (material, light), see shadow_is_moot (RT_TRACE_MOOT_SHADOW_RAYS=1:
+    // every shadow ray is traced, as a cross-check)
+    std::vector<uint32_t> moot_flags((size_t)desc->n_materials * desc->n_lights, 0u);
+    const char* trace_moot = getenv("RT_TRACE_MOOT_SHADOW_RAYS");
+    if (!(trace_moot && atoi(trace_moot)))
+        for (uint32_t m = 0; m < desc->n_materials; ++m)
+            for (uint32_t l = 0; l < desc->n_lights; ++l) {
+                const RtMaterial& mat = materials[m];
+                bool d_zero = true, d_finite = true, s_zero = true, s_finite = true;
+                for (int c = 0; c < 3; ++c) {
+                    const float d = lights[l].diffuse[c] * mat.diffuse[c], sp = lights[l].specular[c] * mat.specular[c];   // as cmul in phong_pass
+                    d_zero = d_zero && d == 0.0f;  d_finite = d_finite && std::isfinite(d);
+                    s_zero = s_zero && sp == 0.0f; s_finite = s_finite && std::isfinite(sp);
+                }
+                moot_flags[(size_t)m * desc->n_lights + l] = (d_zero ? RT_MOOT_DIFFUSE_ZERO : 0u) | (d_finite ? RT_MOOT_DIFFUSE_FINITE : 0u) |
+                                                             (s_zero && mat.shininess >= 0.0f ? RT_MOOT_SPECULAR_ZERO : 0u) |
+                                                             (s_finite && mat.shininess > 0.0f ? RT_MOOT_SPECULAR_FINITE : 0u);
+            }
     std::vector<DPlane> planes(desc->n_planes);
     for (uint32_t i = 0; i < desc->n_planes; ++i) {
         const RtPlane& p = desc->planes[i];
@@ -578,7 +596,7 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device_id, RtScene**
         (rc = upload(s, triangles, &s->d.triangles)) || (rc = upload(s, instances, &s->d.instances)) ||
         (rc = upload(s, range_nodes, &s->d.range_nodes)) || (rc = upload(s, range_limits, &s->d.range_limits)) ||
         (rc = upload(s, nodes, &s->d.nodes)) || (rc = upload(s, nodes4, &s->d.nodes4)) || (rc = upload(s, hot, &s->d.tri_hot)) || (rc = upload(s, cold, &s->d.tri_cold)) ||
-        (rc = upload(s, leaf_boxes, &s->d.leaf_boxes)))
+        (rc = upload(s, leaf_boxes, &s->d.leaf_boxes)) || (rc = upload(s, moot_flags, &s->d.moot_flags)))
         return bail(rc);
     // five blocks per compute unit for the list kernels (measured on the 1080p bunnies frame: 4: 3.02 ms, 5: 2.93 ms,
     // 6: 2.94 ms with rt_shade squeezed into 80 registers, 8: 3.6 ms)

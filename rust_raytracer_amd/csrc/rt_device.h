@@ -136,7 +136,15 @@ struct DScene {
     // box), so "the leaves whose own box the ray passes" are exactly the leaves the reference's walk tests.
     uint32_t n_leaf_boxes;
     const float4* leaf_boxes;
+    // Per (material, light), at [material * n_lights + light]: what radiance() (raytracer.rs:137-153) can do with a shadow
+    // verdict, RT_MOOT_* - see shadow_is_moot in rt_kernels.hip.  All zero: every shadow ray is traced.
+    const uint32_t* moot_flags;
 };
+
+#define RT_MOOT_DIFFUSE_ZERO 1u       // light.diffuse * material.diffuse is +-0 in every channel
+#define RT_MOOT_DIFFUSE_FINITE 2u     // ... is finite in every channel
+#define RT_MOOT_SPECULAR_ZERO 4u      // light.specular * material.specular is +-0 in every channel and shininess >= 0
+#define RT_MOOT_SPECULAR_FINITE 8u    // ... is finite in every channel and shininess > 0
 
 // The cameras of the views of a frame (rt_generate's own argument): column-major screen_to_world matrices.
 struct DViews { float m[RT_MAX_VIEWS][16]; };

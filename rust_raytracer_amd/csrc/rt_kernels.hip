@@ -349,8 +349,7 @@ __device__ __forceinline__ RayRec load_rec(const float4* q, uint32_t i) {
 // Shadow rays are not stored: the shadow ray of hit record `hs` towards light `li` (ray slot shadow_base + hs * n_lights
 // + li) is rebuilt from the record wherever it is needed - trace_shadow_ray's own arithmetic (raytracer.rs:158-167) on the
 // stored hit position, so the same bits every time.
-__device__ __forceinline__ RayRec shadow_rec(const DScene& S, const float4* hits, uint32_t hs, uint32_t li) {
-    const float4 h0 = hits[3 * (size_t)hs];
+__device__ __forceinline__ RayRec shadow_rec_of(const DScene& S, const float4 h0, uint32_t li) {
     const DLight& L = S.lights[li];
     const V3 position = mk(h0.x, h0.y, h0.z);
     const V3 dir = (L.pos[3] == 0.0f) ? mk(L.pos[0], L.pos[1], L.pos[2]) : ld3(L.world) - position;
@@ -360,6 +359,36 @@ __device__ __forceinline__ RayRec shadow_rec(const DScene& S, const float4* hits
     rr.throughput = 0.0f;
     rr.meta = RT_RAY_SHADOW_BIT | li;
     return rr;
+}
+__device__ __forceinline__ RayRec shadow_rec(const DScene& S, const float4* hits, uint32_t hs, uint32_t li) {
+    return shadow_rec_of(S, hits[3 * (size_t)hs], li);
+}
+
+// The two cosines of radiance() (raytracer.rs:139-145) for the unit vector l towards the light: the one place they are
+// computed, so that whoever asks gets the same bits.
+__device__ __forceinline__ void phong_cosines(V3 l, V3 n, V3 view, float& l_dot_n, float& r_dot_v) {
+    const V3 rv = reflected_dir(l, n);
+    l_dot_n = fmaxf(dot3(l, n), 0.0f);
+    r_dot_v = fmaxf(dot3(rv, view), 0.0f);
+}
+
+// A shadow ray's verdict only ever switches the diffuse and the specular term of radiance() off (raytracer.rs:149-150).
+// Where both are zero anyway - the surface faces away from the light (l.n <= 0, so the product with the clamped cosine is
+// 0) or the colour product is zero, and likewise the mirrored light direction faces away from the viewer (0 to a positive
+// power) - tracing the ray cannot change a bit of the picture, and it is not traced: its key stays "no hit".  The
+// conditions are on the very floats the Phong sum uses later (phong_cosines on the stored hit record), and the products
+// must not turn 0 * x into NaN, hence the finiteness flags.  Shadow rays of primary hits are traced regardless when the
+// caller wants the per-pixel flags, which report the verdict itself (RT_FLAG_SHADOW_LIGHT0).
+__device__ __forceinline__ bool shadow_is_moot(const DScene& S, const DFrame& F, const float4* hit, uint32_t li, V3 l) {
+    const uint32_t flags = S.moot_flags[__float_as_uint(hit[0].w) * S.n_lights + li];
+    if (!flags) return false;
+    const float4 h1 = hit[1], h2 = hit[2];
+    if (F.aux_flags && (__float_as_uint(h2.w) & 0x80000000u)) return false;       // RT_HIT_DEPTH0
+    float l_dot_n, r_dot_v;
+    phong_cosines(l, mk(h1.x, h1.y, h1.z), mk(h2.x, h2.y, h2.z), l_dot_n, r_dot_v);
+    const bool diffuse_fixed = ((flags & RT_MOOT_DIFFUSE_ZERO) && l_dot_n < RT_INF) || ((flags & RT_MOOT_DIFFUSE_FINITE) && l_dot_n == 0.0f);
+    const bool specular_fixed = ((flags & RT_MOOT_SPECULAR_ZERO) && r_dot_v <= 1.0f) || ((flags & RT_MOOT_SPECULAR_FINITE) && r_dot_v == 0.0f);
+    return diffuse_fixed && specular_fixed;
 }
 // Any ray of recursion depth `level` by its slot: listed rays from the ray list, shadow rays from the hits of the depth above.
 __device__ __forceinline__ RayRec load_any_rec(const DScene& S, const DFrame& F, uint32_t level, uint32_t gi) {
@@ -843,6 +872,11 @@ __device__ unsigned long long g_shade_timing[8192 * 8];
 // per wave of the last launch that set rays up (rt_setup, or rt_shade with setup_next): cycles spent fetching the rays of its
 // chunks, on the analytic primitives, on the culling boxes, pushing and draining pairs; chunks; drains
 __device__ unsigned long long g_setup_timing[8192 * 8];
+// shadow rays per depth: [2 * depth] set up, [2 * depth + 1] of them not traced (shadow_is_moot); never reset
+__device__ unsigned long long g_moot_counts[2 * (RT_MAX_DEPTH_LIMIT + 2)];
+extern "C" hipError_t rt_debug_moot_counts(unsigned long long* out, size_t n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_moot_counts), n * sizeof(unsigned long long));
+}
 extern "C" hipError_t rt_debug_setup_timing(unsigned long long* out, size_t n) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_setup_timing), n * sizeof(unsigned long long));
 }
@@ -974,7 +1008,21 @@ __device__ __forceinline__ void setup_rays(const DScene& S, const DFrame& F, con
             uint32_t hs;
             if (LOCAL) hs = v < in.own_hits ? blockIdx.x * F.seg_hits + v : (active ? in.extra_hits[v - in.own_hits] : 0u);
             else hs = locate_chunk(in.pre_hits, F.n_seg, F.seg_hits, first, in.n_hits, lane);
-            if (active) { gi = F.shadow_base + hs * S.n_lights + light; rr = shadow_rec(S, F.hits[p ^ 1], hs, light); }
+            if (active) {
+                gi = F.shadow_base + hs * S.n_lights + light;
+                const float4* hit = F.hits[p ^ 1] + 3 * (size_t)hs;
+                rr = shadow_rec_of(S, hit[0], light);
+                if (shadow_is_moot(S, F, hit, light, rr.ray.d)) {       // nobody needs this ray's verdict
+                    L.best[gi] = RT_KEY_NONE;
+                    active = false;
+                }
+            }
+#ifdef RT_STATS
+            {
+                const unsigned long long all = __ballot(v < in.n_hits), moot = all & ~__ballot(active);
+                if (lane == 0) { atomicAdd(&g_moot_counts[2 * level], (unsigned long long)__popcll(all)); atomicAdd(&g_moot_counts[2 * level + 1], (unsigned long long)__popcll(moot)); }
+            }
+#endif
         }
         if (active && c < main_chunks) rr = load_rec(rays, gi);
         const Ray r = rr.ray;
@@ -2043,9 +2091,8 @@ __device__ void phong_pass(const DScene& S, const DFrame& F, const uint32_t leve
                                    (directional || __uint_as_float((uint32_t)(key >> 32)) < distance3(position, ld3(L.world)));
             if (is_shadow && li < 4) shadow_bits |= RT_FLAG_SHADOW_LIGHT0 << li;
             V3 l = normalize3(directional ? mk(L.pos[0], L.pos[1], L.pos[2]) : ld3(L.world) - position);   // raytracer.rs:209-220
-            V3 rv = reflected_dir(l, n);
-            float l_dot_n = fmaxf(dot3(l, n), 0.0f);
-            float r_dot_v = fmaxf(dot3(rv, view), 0.0f);
+            float l_dot_n, r_dot_v;
+            phong_cosines(l, n, view, l_dot_n, r_dot_v);
             V3 emissive = ld3(mat.emissive);
             V3 ambient = cmul(ld3(L.ambient), ld3(mat.ambient));
             V3 zero = mk(0.0f, 0.0f, 0.0f);

@@ -1014,7 +1014,7 @@ def test_api_errors(scenes_dir, model_dir):
         fp = mats.ctypes.data_as(C.POINTER(C.c_float))
         assert L.rt_scene_set_views(dev._h, fp, 0, w, h) == abi.RT_ERR_INVALID_ARGUMENT
         assert L.rt_scene_set_views(dev._h, fp, abi.RT_MAX_VIEWS + 1, w, h) == abi.RT_ERR_INVALID_ARGUMENT
-        assert L.rt_scene_set_views(dev._h, fp, 8, 4096, 4096) == 0
+        assert L.rt_scene_set_views(dev._h, fp, 32, 4096, 4096) == 0
         assert L.rt_shard_bytes(dev._h, C.byref(p), C.byref(n)) == abi.RT_ERR_INVALID_ARGUMENT and b"pixels" in L.rt_last_error()
         dev.set_camera(m, w, h)
         assert L.rt_render(dev._h, C.byref(p), out.ctypes.data, None) == 0                                # and it still works
