@@ -386,7 +386,7 @@ def main():
     barrier()
 
     t = torch.tensor([elapsed, elapsed_sequential], dtype=torch.float64, device="cuda")
-    rays = torch.tensor(np.concatenate([counts, own_counts[:5], own_counts[[abi.RT_CTR_WALK_NODE_VISITS, abi.RT_CTR_WALK_TRIANGLE_TESTS]]]),
+    rays = torch.tensor(np.concatenate([counts, own_counts[:5], own_counts[[abi.RT_CTR_WALK_NODE_VISITS, abi.RT_CTR_WALK_TRIANGLE_TESTS, abi.RT_CTR_SHADOW_NOT_TRACED]]]),
                         dtype=torch.int64, device="cuda")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -505,6 +505,9 @@ def main():
                        "rays_in_timed_region": int(region_rays[0]), "mean_rays_per_frame": int(region_rays[0]) / max(args.steps, 1),
                        "rays_per_frame": rays_per_frame, "primary": int(frame_rays[1]), "shadow": int(frame_rays[2]),
                        "reflected": int(frame_rays[3]), "transmitted": int(frame_rays[4]),
+                       # rays are counted as the reference traces them; of the shadow rays, these were settled without a trace
+                       # because their verdict cannot change the picture (RT_CTR_SHADOW_NOT_TRACED in include/rt_hip.h)
+                       "shadow_not_traced": int(rays[12]),
                        "frames_in_flight": depth * views, "passes_in_flight": depth, "views_per_pass": views,
                        "list_bytes_per_pass": list_use["bytes"], "list_bytes_per_view": list_use["bytes"] // max(views, 1),
                        "parallelism": ("tile-sharded x%d, scene replicated, %s" % (world, "REHEARSAL: ranks share one GPU, gloo"

@@ -38,7 +38,7 @@ use crate::Scene;
 }
 #[repr(C)] pub struct RtRenderParams { pub max_depth: u32, pub output_format: u32, pub shard_index: u32, pub shard_count: u32,
                                        pub mode: u32, pub reserved: u32, pub stream: *mut c_void }
-pub const RT_N_COUNTERS: usize = 16;
+pub const RT_N_COUNTERS: usize = 17;
 pub const RT_N_LIST_USE: usize = 7;
 #[repr(C)] pub struct RtAux { pub prim_id: *mut u32, pub instance_id: *mut u32, pub flags: *mut u8, pub counters: [u64; RT_N_COUNTERS], pub hit_t: *mut f32 }
 pub enum RtScene {}

@@ -190,6 +190,11 @@ enum {
     /* (ray, instance) pairs whose ray enters the mesh so far out that it passes nearly every box: tested against every
      * leaf by a block of their own instead of being walked (their box and triangle tests are in the two counters above) */
     RT_CTR_WALK_HEAVY_PAIRS,
+    /* shadow rays (counted in RT_CTR_SHADOW and RT_CTR_RAYS like every ray the reference traces) that were not traced because
+     * their verdict could not change a bit of the picture: radiance() (raytracer.rs:137-153) only uses it to switch the
+     * diffuse and the specular term off, and both were zero already - the surface faces away from the light and the
+     * mirrored light direction away from the viewer, or the colour products are zero */
+    RT_CTR_SHADOW_NOT_TRACED,
     RT_N_COUNTERS
 };
 

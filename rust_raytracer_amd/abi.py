@@ -24,10 +24,10 @@ RT_FLAG_HIT, RT_FLAG_FRONTSIDE, RT_FLAG_REFLECTION_HIT, RT_FLAG_REFRACTION_HIT, 
 (RT_CTR_RAYS, RT_CTR_PRIMARY, RT_CTR_SHADOW, RT_CTR_REFLECTED, RT_CTR_TRANSMITTED, RT_CTR_AABB_TESTS,
  RT_CTR_MESH_TRIANGLE_TESTS, RT_CTR_TRIANGLE_TESTS, RT_CTR_SPHERE_TESTS, RT_CTR_PLANE_TESTS,
  RT_CTR_INSTANCE_TRANSFORMS, RT_CTR_MESH_HITS, RT_CTR_LIGHT_SHADES, RT_CTR_WALK_NODE_VISITS, RT_CTR_WALK_TRIANGLE_TESTS,
- RT_CTR_WALK_HEAVY_PAIRS, RT_N_COUNTERS) = range(17)
+ RT_CTR_WALK_HEAVY_PAIRS, RT_CTR_SHADOW_NOT_TRACED, RT_N_COUNTERS) = range(18)
 COUNTER_NAMES = ["rays", "primary", "shadow", "reflected", "transmitted", "aabb_tests", "mesh_triangle_tests",
                  "triangle_tests", "sphere_tests", "plane_tests", "instance_transforms", "mesh_hits", "light_shades",
-                 "walk_node_visits", "walk_triangle_tests", "walk_heavy_pairs"]
+                 "walk_node_visits", "walk_triangle_tests", "walk_heavy_pairs", "shadow_not_traced"]
 (RT_LIST_USE_BYTES, RT_LIST_USE_RAY_SLOTS, RT_LIST_USE_WALK_SLOTS, RT_LIST_USE_HIT_SLOTS, RT_LIST_USE_RAYS,
  RT_LIST_USE_WALK_ITEMS, RT_LIST_USE_HITS, RT_N_LIST_USE) = range(8)
 LIST_USE_NAMES = ["bytes", "ray_slots", "walk_slots", "hit_slots", "rays", "walk_items", "hits"]

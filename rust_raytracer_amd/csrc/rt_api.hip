@@ -1223,7 +1223,9 @@ extern "C" int rt_last_ray_counts(RtScene* s, uint64_t counters[RT_N_COUNTERS]) 
     if (rc) return rc;
     if ((rc = measure_lists(s))) return rc;
     for (int k = 0; k < RT_N_COUNTERS; ++k) counters[k] = 0;
-    for (int k = 0; k < 5; ++k) counters[k] = sums[k];
+    // a wave's row: [0] shadow rays not traced, [1..4] primary, shadow, reflected and transmitted rays, [5..7] the BVH walk
+    for (int k = 1; k < 5; ++k) { counters[k] = sums[k]; counters[RT_CTR_RAYS] += sums[k]; }
+    counters[RT_CTR_SHADOW_NOT_TRACED] = sums[0];
     counters[RT_CTR_WALK_NODE_VISITS] = sums[5];
     counters[RT_CTR_WALK_TRIANGLE_TESTS] = sums[6];
     counters[RT_CTR_WALK_HEAVY_PAIRS] = sums[7];

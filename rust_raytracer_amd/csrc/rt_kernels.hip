@@ -972,6 +972,7 @@ __device__ __forceinline__ void setup_rays(const DScene& S, const DFrame& F, con
     R.head = 0; R.count = 0;
     uint32_t& out_n = *out_n_ptr;
     uint32_t& slow_n = *slow_n_ptr;
+    uint32_t n_moot = 0;                       // shadow rays this lane did not trace (shadow_is_moot)
 
     // Chunks of 64 rays: first the listed rays, then, light by light, the shadow rays of the hit records (a chunk
     // never mixes the two kinds, nor two lights).
@@ -1015,6 +1016,7 @@ __device__ __forceinline__ void setup_rays(const DScene& S, const DFrame& F, con
                 if (shadow_is_moot(S, F, hit, light, rr.ray.d)) {       // nobody needs this ray's verdict
                     L.best[gi] = RT_KEY_NONE;
                     active = false;
+                    ++n_moot;
                 }
             }
 #ifdef RT_STATS
@@ -1138,6 +1140,10 @@ __device__ __forceinline__ void setup_rays(const DScene& S, const DFrame& F, con
     }
 #endif
     while (R.count) ring_drain(R, S, F, L, &out_n, lane);           // the pairs still waiting
+    {   // column 0 of the wave's row of statistics (the grid's waves own a row each, see rt_shade)
+        for (int off = 32; off > 0; off >>= 1) n_moot += __shfl_down(n_moot, off);
+        if (lane == 0 && n_moot) F.wave_stats[(size_t)((blockIdx.x * blockDim.x + threadIdx.x) / RT_WAVE) * 8] += n_moot;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         L.fat_counts[blockIdx.x] = out_n < F.seg_fat ? out_n : F.seg_fat;
@@ -2287,11 +2293,11 @@ __global__ void __launch_bounds__(RT_SHADE_THREADS) rt_shade(const DScene S, con
 #endif
     // ---- ray statistics: every wave owns a row of F.wave_stats (no atomics) ----------------------------
     {
-        uint32_t vals[5] = {n_primary + n_shadow + n_reflected + n_transmitted, n_primary, n_shadow, n_reflected, n_transmitted};
-        for (int k = 0; k < 5; ++k) {
+        uint32_t vals[4] = {n_primary, n_shadow, n_reflected, n_transmitted};      // columns 1..4 (column 0: setup_rays)
+        for (int k = 0; k < 4; ++k) {
             uint32_t x = vals[k];
             for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
-            if (lane == 0 && x) F.wave_stats[(size_t)gwave * 8 + k] += x;
+            if (lane == 0 && x) F.wave_stats[(size_t)gwave * 8 + 1 + k] += x;
         }
     }
     __syncthreads();

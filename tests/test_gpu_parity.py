@@ -582,6 +582,41 @@ def test_five_4k_views_in_one_pass(scenes_dir, model_dir):
         host.close()
 
 
+def test_shadow_rays_nobody_needs_are_not_traced(scenes_dir, model_dir, monkeypatch):
+    """A shadow ray whose verdict cannot change the Phong sum - the surface faces away from the light and the mirrored light
+    direction away from the viewer, or the colour products are zero - is counted but not traced (RT_CTR_SHADOW_NOT_TRACED).
+    The picture must be the same bytes as with every shadow ray traced (RT_TRACE_MOOT_SHADOW_RAYS=1 at scene creation),
+    the ray counts the reference's; and when the caller asks for the per-pixel flags, which report the verdicts of the
+    primary hits themselves, those rays are traced and the flags are the oracle's."""
+    import torch
+    s = load(scenes_dir, model_dir, "reflective_bunnies", 960, 540)
+    m, w, h = s.camera()
+    want = s.render()
+    monkeypatch.setenv("RT_TRACE_MOOT_SHADOW_RAYS", "1")
+    every = native.DeviceScene(s.desc(), 0)
+    monkeypatch.delenv("RT_TRACE_MOOT_SHADOW_RAYS")
+    dev = native.DeviceScene(s.desc(), 0)
+    try:
+        out = [torch.zeros(h * w * 3, dtype=torch.uint8, device="cuda") for _ in range(2)]
+        counts = []
+        for k, d in enumerate((every, dev)):
+            d.set_camera(m, w, h)
+            d.render_device(out[k].data_ptr())
+            counts.append(d.last_ray_counts())
+        assert torch.equal(out[0], out[1])
+        assert counts[0][:5].tolist() == counts[1][:5].tolist() == [int(x) for x in want["counters"][:5]]
+        assert counts[0][abi.RT_CTR_SHADOW_NOT_TRACED] == 0
+        assert counts[1][abi.RT_CTR_SHADOW_NOT_TRACED] > counts[1][abi.RT_CTR_SHADOW] // 10
+        assert counts[1][abi.RT_CTR_WALK_NODE_VISITS] < counts[0][abi.RT_CTR_WALK_NODE_VISITS]
+        got = dev.render(aux=True)                                        # with the flags: the primary hits' shadow rays are traced
+        assert_parity(got, want)
+        skipped_with_flags = int(got["counters"][abi.RT_CTR_SHADOW_NOT_TRACED])
+        assert 0 < skipped_with_flags < counts[1][abi.RT_CTR_SHADOW_NOT_TRACED]
+    finally:
+        every.close()
+        dev.close()
+
+
 def test_stray_rays_switch_the_exact_path_on(scenes_dir, model_dir):
     """The kernel that traces rays with non-finite components in the reference's own order is left out of the launch
     sequence until a frame turns out to hold such rays (here: a camera matrix with a NaN in it, so that every primary
