@@ -138,6 +138,9 @@ hipError_t hipStreamSynchronize(hipStream_t s);
 hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned int flags);
 hipError_t hipDeviceSynchronize();
 hipError_t hipMemGetInfo(size_t* free_bytes, size_t* total_bytes);
+// scoped atomic loads: the emulated device is one thread at a time, any scope is the same load
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __hip_atomic_load(ptr, order, scope) __atomic_load_n(ptr, order)
 hipError_t hipEventCreate(hipEvent_t* e);
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned int flags);
 hipError_t hipEventDestroy(hipEvent_t e);
