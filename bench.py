@@ -123,7 +123,7 @@ def cpu_baseline(scene_path, model_dir, width, height, max_depth, budget_s=15.0)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=48)
+    ap.add_argument("--steps", type=int, default=96)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--repeats", type=int, default=7, help="times the timed region of --steps frames is run; the median is reported")
     ap.add_argument("--workload", default="reflective_bunnies_1080p", choices=sorted(WORKLOADS))
@@ -208,9 +208,9 @@ def main():
     # tables, the longest BVH walk - is paid once for all of them, which matters most for the small shards of many ranks.
     views = args.views_per_pass
     if views <= 0:
-        # as many as make sixteen 1080p frames' worth of pixels per rank (the library takes up to 2^25 pixels per pass),
-        # leaving at least two passes to overlap
-        cap = max(1, min(abi.RT_MAX_VIEWS, 16 * 1920 * 1080 * world // (w * h)))
+        # as many as make thirty-two 1080p frames' worth of pixels per rank (measured on the headline frame: 16 views per pass
+        # 15.9 Grays/s, 24: 16.2, 32: 16.2; the library takes up to 2^28 pixels per pass), leaving at least two passes to overlap
+        cap = max(1, min(abi.RT_MAX_VIEWS, 32 * 1920 * 1080 * world // (w * h)))
         views = max([v for v in range(1, cap + 1) if args.steps // v >= 2] or [1])
     views = max(1, min(views, abi.RT_MAX_VIEWS, max(args.steps, 1)))
     passes, leftover = divmod(args.steps, views)       # the frames that do not fill a pass get a smaller pass of their own
@@ -285,7 +285,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Set-up, not warm-up: the first pass on a handle allocates its ray lists, the first gather creates the
+    # Set-up, not warm-up.  A handle sizes its work lists by what its frames have held (rt_last_list_use): one frame of the
+    # pass's first camera, counted, and the lists of the whole pass are made the right length at once - instead of four
+    # rays per pixel and depth first, which for three passes of 32 views would be most of the device's memory.
+    probe = torch.empty(w * h * 3, dtype=torch.uint8, device="cuda")
+    for s in every_slot:
+        s.dev.set_views(np.stack(s.cams[:1]), w, h)
+        for attempt in range(4):
+            s.dev.render_device(probe.data_ptr(), max_depth=max_depth, shard_index=rank, shard_count=world, stream=s.stream.cuda_stream)
+            try:
+                s.dev.last_ray_counts()
+                break
+            except native.RtError:
+                if attempt == 3:
+                    raise
+        s.dev.set_views(np.stack(s.cams), w, h)
+    del probe
+    # Then the passes themselves: the first one on a handle allocates its ray lists, the first gather creates the
     # communicator, and a pass whose ray lists overflow makes the next one on that handle allocate longer ones.
     for s in every_slot:
         for attempt in range(6):
