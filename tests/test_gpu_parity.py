@@ -27,6 +27,10 @@ def render_both(oscene, max_depth=10, queue_capacity=0):
             dev.debug_set_queue_capacity(queue_capacity)
         got = dev.render(max_depth=max_depth, aux=True)
         got["regrown"] = dev.debug_last_regrown()
+        # Without the per-pixel flags the shadow rays of primary hits whose verdict cannot matter go untraced as well (with
+        # them, only those of deeper hits): the picture has to be the same bytes either way.
+        plain = dev.render(max_depth=max_depth)
+        assert np.array_equal(plain["rgb"], got["rgb"]), "picture differs on %d pixels without the flags" % (plain["rgb"] != got["rgb"]).any(axis=-1).sum()
     finally:
         dev.close()
     want = oscene.render(max_depth=max_depth)
@@ -843,6 +847,45 @@ def test_random_scenes(tmp_path_factory, block):
         except AssertionError as e:
             raise AssertionError("seed %d: %s" % (seed, e))
     print("random scenes %d..%d: worst share of pixels within 1 LSB %.5f" % (block * 12, block * 12 + 11, worst))
+
+
+def test_shadow_ray_elision_with_odd_materials(tmp_path_factory):
+    """Whether a shadow ray's verdict can matter is decided from the colour products and the shininess (shadow_is_moot in
+    rt_kernels.hip): zero products make every verdict moot, infinite or NaN ones none (0 * inf is NaN, and radiance(),
+    raytracer.rs:137-153, would compute just that), a shininess of zero or below turns 0^s into 1 or infinity.  The fuzz
+    scenes with such materials and lights written into the scene description in place: flags, ids and counts are the
+    oracle's, the picture within the usual bar, and the same bytes with and without the per-pixel flags (render_both)."""
+    from rust_raytracer_amd import synthetic
+    d = str(tmp_path_factory.mktemp("odd_materials"))
+    inf, nan = float("inf"), float("nan")
+    spoil = [lambda m: m.diffuse.__setitem__(0, inf),
+             lambda m: (m.specular.__setitem__(1, inf), setattr(m, "shininess", 0.0)),
+             lambda m: setattr(m, "shininess", -2.0),
+             lambda m: [m.diffuse.__setitem__(c, 0.0) or m.specular.__setitem__(c, 0.0) for c in range(3)],
+             lambda m: m.specular.__setitem__(2, nan),
+             lambda m: setattr(m, "shininess", inf),
+             lambda m: [m.diffuse.__setitem__(c, 0.0) for c in range(3)],
+             lambda m: (m.specular.__setitem__(0, -0.0), m.specular.__setitem__(1, 0.0), m.specular.__setitem__(2, 0.0), setattr(m, "shininess", 0.0))]
+    skipped = 0
+    for seed in range(500, 512):
+        s = orc.OracleScene.from_text(synthetic.random_scene(d, seed), d)
+        desc = s.desc()
+        for k in range(desc.n_materials):
+            if (seed + k) % 3 != 2:
+                spoil[(seed + k) % len(spoil)](desc.materials[k])                 # the oracle's own arrays, in place
+        for k in range(desc.n_lights):
+            if (seed + k) % 4 == 0:
+                for c in range(3):
+                    desc.lights[k].diffuse[c] = 0.0
+            if (seed + k) % 5 == 0:
+                desc.lights[k].specular[0] = inf
+        got, want = render_both(s, max_depth=5)
+        try:
+            assert_parity(got, want, min_within_1=0.999)
+        except AssertionError as e:
+            raise AssertionError("seed %d: %s" % (seed, e))
+        skipped += int(got["counters"][abi.RT_CTR_SHADOW_NOT_TRACED])
+    assert skipped > 0
 
 
 @pytest.mark.parametrize("block", range(3))
