@@ -140,6 +140,11 @@ def main():
                     help="with --gpus 1: initialise the RCCL process group (world size 1) and send every pass through all_gather_into_tensor + assemble")
     ap.add_argument("--watchdog", type=int, default=900, help="seconds after which a stuck run prints its stacks and exits non-zero (0 = off)")
     args = ap.parse_args()
+    # stdout is for the one JSON line: whatever libraries print on the way (RCCL's version banner when a communicator is
+    # created) goes to stderr instead
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     if args.watchdog:
         # a gather that never completes must end the run with a failure, not hang the box: dump the stacks and _exit(1)
         import faulthandler
@@ -544,7 +549,9 @@ def main():
         if args.exercise_collective:
             out["collective_exercised"] = "every pass of the timed region went through all_gather_into_tensor on an RCCL process group of world size %d and the assemble step" % world
         out["frame_checksum"] = int(np.asarray(frame_check, dtype=np.uint64).sum())
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)                 # the one line this program prints
+        print(json.dumps(out), flush=True)
     for s in every_slot:
         s.dev.close()
     if world > 1:

@@ -379,10 +379,9 @@ __device__ __forceinline__ void phong_cosines(V3 l, V3 n, V3 view, float& l_dot_
 // conditions are on the very floats the Phong sum uses later (phong_cosines on the stored hit record), and the products
 // must not turn 0 * x into NaN, hence the finiteness flags.  Shadow rays of primary hits are traced regardless when the
 // caller wants the per-pixel flags, which report the verdict itself (RT_FLAG_SHADOW_LIGHT0).
-__device__ __forceinline__ bool shadow_is_moot(const DScene& S, const DFrame& F, const float4* hit, uint32_t li, V3 l) {
-    const uint32_t flags = S.moot_flags[__float_as_uint(hit[0].w) * S.n_lights + li];
+__device__ __forceinline__ bool shadow_is_moot(const DScene& S, const DFrame& F, const float4 h0, const float4 h1, const float4 h2, uint32_t li, V3 l) {
+    const uint32_t flags = S.moot_flags[__float_as_uint(h0.w) * S.n_lights + li];
     if (!flags) return false;
-    const float4 h1 = hit[1], h2 = hit[2];
     if (F.aux_flags && (__float_as_uint(h2.w) & 0x80000000u)) return false;       // RT_HIT_DEPTH0
     float l_dot_n, r_dot_v;
     phong_cosines(l, mk(h1.x, h1.y, h1.z), mk(h2.x, h2.y, h2.z), l_dot_n, r_dot_v);
@@ -973,6 +972,9 @@ __device__ __forceinline__ void setup_rays(const DScene& S, const DFrame& F, con
     uint32_t& out_n = *out_n_ptr;
     uint32_t& slow_n = *slow_n_ptr;
     uint32_t n_moot = 0;                       // shadow rays this lane did not trace (shadow_is_moot)
+#ifdef RT_STATS
+    uint32_t dbg_shadow_rays = 0;              // shadow rays this lane has looked at
+#endif
 
     // Chunks of 64 rays: first the listed rays, then, light by light, the shadow rays of the hit records (a chunk
     // never mixes the two kinds, nor two lights).
@@ -1012,18 +1014,16 @@ __device__ __forceinline__ void setup_rays(const DScene& S, const DFrame& F, con
             if (active) {
                 gi = F.shadow_base + hs * S.n_lights + light;
                 const float4* hit = F.hits[p ^ 1] + 3 * (size_t)hs;
-                rr = shadow_rec_of(S, hit[0], light);
-                if (shadow_is_moot(S, F, hit, light, rr.ray.d)) {       // nobody needs this ray's verdict
+                const float4 h0 = hit[0], h1 = hit[1], h2 = hit[2];      // requested together: one trip to memory, not three
+                rr = shadow_rec_of(S, h0, light);
+                if (shadow_is_moot(S, F, h0, h1, h2, light, rr.ray.d)) {       // nobody needs this ray's verdict
                     L.best[gi] = RT_KEY_NONE;
                     active = false;
                     ++n_moot;
                 }
             }
 #ifdef RT_STATS
-            {
-                const unsigned long long all = __ballot(v < in.n_hits), moot = all & ~__ballot(active);
-                if (lane == 0) { atomicAdd(&g_moot_counts[2 * level], (unsigned long long)__popcll(all)); atomicAdd(&g_moot_counts[2 * level + 1], (unsigned long long)__popcll(moot)); }
-            }
+            dbg_shadow_rays += v < in.n_hits ? 1u : 0u;
 #endif
         }
         if (active && c < main_chunks) rr = load_rec(rays, gi);
@@ -1142,6 +1142,13 @@ __device__ __forceinline__ void setup_rays(const DScene& S, const DFrame& F, con
     while (R.count) ring_drain(R, S, F, L, &out_n, lane);           // the pairs still waiting
     {   // column 0 of the wave's row of statistics (the grid's waves own a row each, see rt_shade)
         for (int off = 32; off > 0; off >>= 1) n_moot += __shfl_down(n_moot, off);
+#ifdef RT_STATS
+        for (int off = 32; off > 0; off >>= 1) dbg_shadow_rays += __shfl_down(dbg_shadow_rays, off);
+        if (lane == 0 && dbg_shadow_rays) {                        // one pair of atomics per wave
+            atomicAdd(&g_moot_counts[2 * level], (unsigned long long)dbg_shadow_rays);
+            atomicAdd(&g_moot_counts[2 * level + 1], (unsigned long long)n_moot);
+        }
+#endif
         if (lane == 0 && n_moot) F.wave_stats[(size_t)((blockIdx.x * blockDim.x + threadIdx.x) / RT_WAVE) * 8] += n_moot;
     }
     __syncthreads();
