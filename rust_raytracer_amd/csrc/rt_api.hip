@@ -18,7 +18,8 @@
 
 extern "C" {
 hipError_t rt_launch_generate(const DFrame* F, const DViews* V, uint32_t blocks, hipStream_t stream);
-hipError_t rt_launch_level(const DScene* S, const DFrame* F, uint32_t level, uint32_t last, uint32_t blocks, uint32_t traverse_blocks,
+int rt_query_setup_blocks_per_cu(const DScene* S, uint32_t n_seg);
+hipError_t rt_launch_level(const DScene* S, const DFrame* F, uint32_t level, uint32_t last, uint32_t blocks, uint32_t setup_blocks, uint32_t traverse_blocks,
                            hipStream_t stream, hipEvent_t* marks);      // launches rt_setup_slow iff F->slow_launched
 hipError_t rt_launch_resolve(const DFrame* F, uint8_t* out, uint32_t bytes_per_pixel, uint32_t tiled, hipStream_t stream);
 hipError_t rt_launch_resolve_aux(const DFrame* F, uint32_t* prim, uint32_t* inst, uint8_t* flags, float* hit_t, hipStream_t stream);
@@ -58,7 +59,8 @@ struct RtScene {
     bool timed = false;
     hipStream_t last_stream = nullptr;
     int n_cus = 0;
-    uint32_t list_blocks = 0;           // grid of the list-producing kernels
+    uint32_t list_blocks = 0;           // grid of the list-producing kernels (= list segments per list)
+    uint32_t setup_blocks = 0;          // grid of rt_setup where it is a kernel of its own: what is resident at once
     uint32_t fuse_setup = 1;            // DFrame::fuse_setup (RT_FUSE_SETUP overrides the choice made at creation)
     bool last_fused = false;            // ... as the frame enqueued last had it
     uint32_t traverse_blocks = 0;       // grid of the BVH walk
@@ -598,15 +600,21 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device_id, RtScene**
         (rc = upload(s, nodes, &s->d.nodes)) || (rc = upload(s, nodes4, &s->d.nodes4)) || (rc = upload(s, hot, &s->d.tri_hot)) || (rc = upload(s, cold, &s->d.tri_cold)) ||
         (rc = upload(s, leaf_boxes, &s->d.leaf_boxes)) || (rc = upload(s, moot_flags, &s->d.moot_flags)))
         return bail(rc);
-    // five blocks per compute unit for the list kernels (measured on the 1080p bunnies frame: 4: 3.02 ms, 5: 2.93 ms,
-    // 6: 2.94 ms with rt_shade squeezed into 80 registers, 8: 3.6 ms)
-    s->list_blocks = (uint32_t)s->n_cus * 5;
+    // six blocks per compute unit for the list kernels, which is what rt_shade - held to 80 registers - keeps resident
+    // (per queued 1080p bunnies frame: rt_shade 0.796 ms with five blocks and five waves per SIMD, 0.757 with six and six)
+    s->list_blocks = (uint32_t)s->n_cus * 6;
     // rt_shade sets up the rays it makes, block by block - unless the scene has so many instances that rays walk the range
     // tree: what a ray costs then varies too much for a block to be left alone with its own rays (measured: the 2.6 M- and
     // 10.5 M-triangle grids lose 2-3 %, every other workload gains 2-9 % per frame)
     s->fuse_setup = s->d.n_range_nodes == 0 ? 1u : 0u;
     if (const char* env = getenv("RT_FUSE_SETUP")) s->fuse_setup = atoi(env) ? 1u : 0u;
     if (const char* env = getenv("RT_LIST_BLOCKS_PER_CU")) { int v = atoi(env); if (v >= 1 && v <= 8) s->list_blocks = (uint32_t)(s->n_cus * v); }
+    {
+        // rt_setup's prefix tables and pair rings take more LDS per block than six blocks leave: its grid is what fits at once
+        const int setup_bpc = rt_query_setup_blocks_per_cu(&s->d, s->list_blocks + 1);
+        if (setup_bpc < 1) return bail(fail(RT_ERR_DEVICE, "the set-up kernel does not fit a compute unit"));
+        s->setup_blocks = std::min<uint32_t>(s->list_blocks, (uint32_t)(s->n_cus * setup_bpc));
+    }
     int bpc = rt_query_traverse_blocks_per_cu(s->list_blocks + 1, s->d.stack_lds);
     if (bpc < 1) return bail(fail(RT_ERR_DEVICE, "the traversal kernel does not fit a compute unit"));
     if (const char* env = getenv("RT_BLOCKS_PER_CU")) { int v = atoi(env); if (v >= 1 && v <= bpc) bpc = v; }
@@ -1017,7 +1025,7 @@ static int enqueue_frame(RtScene* s, const RtRenderParams* p, bool sharded, bool
         s->marked_levels = last + 1;
     }
     for (uint32_t level = 0; level <= last; ++level)
-        HIP_TRY(rt_launch_level(&s->d, &f, level, last, blocks, s->traverse_blocks, stream,
+        HIP_TRY(rt_launch_level(&s->d, &f, level, last, blocks, std::min(blocks, s->setup_blocks), s->traverse_blocks, stream,
                                 s->marked_levels ? &s->marks[(RT_N_LEVEL_KERNELS + 1) * (size_t)level] : nullptr));
     HIP_TRY(hipEventRecord(s->ev_trace_stop, stream));
     HIP_TRY(rt_launch_resolve(&f, d_out, bytes_per_pixel(p->output_format), g.shard_count > 1 ? 1u : 0u, stream));

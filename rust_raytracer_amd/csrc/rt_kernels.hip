@@ -2124,10 +2124,10 @@ __device__ void phong_pass(const DScene& S, const DFrame& F, const uint32_t leve
 // (raytracer.rs:65-135), except the Phong sum, which has to wait for its shadow rays (phong_pass, one depth later).
 // Shadow rays only record their verdict (raytracer.rs:171-187).
 // ======================================================================================================
-// five waves per SIMD: the kernel needs 97 registers, which the allocation granule would round up to four waves'
-// worth; the list kernels run five blocks per compute unit
+// six waves per SIMD, six blocks per compute unit: left alone the kernel takes 88 registers (five waves); held to 80 it spills
+// four and still gains (0.796 -> 0.757 ms per queued 1080p bunnies frame; four waves without any spill: 1.15 ms)
 #ifndef RT_SHADE_WAVES
-#define RT_SHADE_WAVES 5
+#define RT_SHADE_WAVES 6
 #endif
 __attribute__((amdgpu_waves_per_eu(RT_SHADE_WAVES, RT_SHADE_WAVES)))
 __global__ void __launch_bounds__(RT_SHADE_THREADS) rt_shade(const DScene S, const DFrame F, const uint32_t level, const uint32_t setup_next) {
@@ -2451,7 +2451,18 @@ extern "C" hipError_t rt_launch_generate(const DFrame* F, const DViews* V, uint3
 // `marks`, when not null, are four events recorded before A and after A', B and C (kernel timing mode).
 // With F->fuse_setup, rt_shade also does the next depth's rt_setup (every depth but `last`), and rt_setup itself is only
 // launched at depth 0.
-extern "C" hipError_t rt_launch_level(const DScene* S, const DFrame* F, uint32_t level, uint32_t last, uint32_t blocks,
+// Blocks of rt_setup a compute unit holds at once with lists of n_seg segments: its grid is kept to what is resident in
+// one go (block b fills list segment b, so any grid up to n_seg - 1 works; the segments of blocks that are not launched stay empty).
+extern "C" int rt_query_setup_blocks_per_cu(const DScene* S, uint32_t n_seg) {
+    const size_t setup_words = analytic_stage_words(*S) + setup_work_words(S->range_depth, RT_SETUP_THREADS);
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, rt_setup, RT_SETUP_THREADS,
+                                                     list_lds_bytes(n_seg) + (n_seg + 1 + setup_words) * sizeof(uint32_t)) != hipSuccess)
+        return -1;
+    return n;
+}
+
+extern "C" hipError_t rt_launch_level(const DScene* S, const DFrame* F, uint32_t level, uint32_t last, uint32_t blocks, uint32_t setup_blocks,
                                       uint32_t traverse_blocks, hipStream_t stream, hipEvent_t* marks) {
     const size_t lds = list_lds_bytes(F->n_seg);
 #ifdef RT_STATS
@@ -2461,7 +2472,7 @@ extern "C" hipError_t rt_launch_level(const DScene* S, const DFrame* F, uint32_t
     if (marks) (void)hipEventRecord(marks[0], stream);
     const size_t setup_words = analytic_stage_words(*S) + setup_work_words(S->range_depth, RT_SETUP_THREADS);
     if (level == 0 || !F->fuse_setup)
-        hipLaunchKernelGGL(rt_setup, dim3(blocks), dim3(RT_SETUP_THREADS),
+        hipLaunchKernelGGL(rt_setup, dim3(setup_blocks < blocks ? setup_blocks : blocks), dim3(RT_SETUP_THREADS),
                            lds + (F->n_seg + 1 + setup_words) * sizeof(uint32_t), stream, *S, *F, level);
     // In a scene whose instances all have culling boxes only stray rays (NaN components) reach this kernel, if any:
     // a small grid keeps the usual empty launch cheap.  (Block b continues list segment b, so any grid <= blocks works.)
