@@ -930,15 +930,18 @@ __device__ __forceinline__ void stage_analytic(const DScene& S, uint32_t* stage)
     __syncthreads();
 }
 
-// LDS words behind the staged primitives: the range-tree stacks of the block's lanes and the rings of its waves.
-__device__ __host__ inline size_t setup_work_words(uint32_t range_depth, uint32_t threads) {
-    return (size_t)range_depth * threads + (size_t)(threads / RT_WAVE) * RT_RING_WORDS;
+// LDS words behind the staged primitives: the rings of the block's waves (the scan of the range tree keeps no stack).
+__device__ __host__ inline size_t setup_work_words(uint32_t /*range_depth*/, uint32_t threads) {
+    return (size_t)(threads / RT_WAVE) * RT_RING_WORDS;
 }
 
 // Where a block finds the rays it sets up.
 struct SetupInput {
-    // rt_setup: all segments of the depth's lists, through prefix tables in LDS
+    // rt_setup: all segments of the depth's lists, through a prefix table in LDS - one table, which holds the listed rays'
+    // segments first and is built again for the hit records' when the block has done its chunks of listed rays (`table`,
+    // with `table_scratch` for the scan)
     const uint32_t* pre; const uint32_t* pre_hits;
+    uint32_t* table; uint32_t* table_scratch;
     uint32_t n_rays, n_hits;
     // rt_shade: what this block has just appended - the first own_* entries of its own segments and the slots it took from
     // the shared overflow segments (n_rays = own_rays + number of extra_rays, likewise for the hit records)
@@ -967,7 +970,7 @@ __device__ __forceinline__ void setup_rays(const DScene& S, const DFrame& F, con
     const uint32_t my_wave = LOCAL ? threadIdx.x / RT_WAVE : (blockIdx.x * blockDim.x + threadIdx.x) / RT_WAVE;
     const uint32_t n_waves = LOCAL ? blockDim.x / RT_WAVE : gridDim.x * (blockDim.x / RT_WAVE);
     PairRing R;
-    R.ring = stage + stage_words + S.range_depth * blockDim.x + (threadIdx.x / RT_WAVE) * RT_RING_WORDS;
+    R.ring = stage + stage_words + (threadIdx.x / RT_WAVE) * RT_RING_WORDS;
     R.head = 0; R.count = 0;
     uint32_t& out_n = *out_n_ptr;
     uint32_t& slow_n = *slow_n_ptr;
@@ -986,7 +989,7 @@ __device__ __forceinline__ void setup_rays(const DScene& S, const DFrame& F, con
 #else
 #define RT_SU_MARK(k)
 #endif
-    for (uint32_t c = my_wave; c < all_chunks; c += n_waves) {
+    auto one_chunk = [&](const uint32_t c) {
 #ifdef RT_STATS
         unsigned long long su_t = clock64();
         su[4] += 1;
@@ -1132,6 +1135,16 @@ __device__ __forceinline__ void setup_rays(const DScene& S, const DFrame& F, con
         }
         if (active) L.best[gi] = have ? make_key(best_t, best_order) : RT_KEY_NONE;
         RT_SU_MARK(3)
+    };
+    // Chunk c goes to wave c mod n_waves.  rt_setup does it in two phases, listed rays and hit records, with the table built
+    // again in between (two loops rather than one loop nest: as a nest the kernel spilled 23 registers).
+    if (LOCAL) {
+        for (uint32_t c = my_wave; c < all_chunks; c += n_waves) one_chunk(c);
+    } else {
+        for (uint32_t c = my_wave; c < main_chunks; c += n_waves) one_chunk(c);
+        __syncthreads();                                               // every wave of the block is done with the rays' table
+        build_prefix(L.hit_counts, F.n_seg, F.seg_hits, F.ovf_hits, in.table, in.table_scratch);
+        for (uint32_t c = main_chunks + (my_wave + n_waves - main_chunks % n_waves) % n_waves; c < all_chunks; c += n_waves) one_chunk(c);
     }
 #ifdef RT_STATS
     {
@@ -1168,16 +1181,17 @@ __attribute__((amdgpu_waves_per_eu(5)))
 __global__ void __launch_bounds__(RT_SETUP_THREADS) rt_setup(const DScene S, const DFrame F, const uint32_t level) {
     const LevelLists L = level_lists(F, level);
     extern __shared__ uint32_t lds[];
-    uint32_t* pre = lds;                                   // n_seg + 1
+    uint32_t* pre = lds;                                   // n_seg + 1: the listed rays' segments, later the hit records' (setup_rays)
     uint32_t* scratch = lds + F.n_seg + 1;                 // blockDim.x
-    uint32_t* pre_hits = scratch + blockDim.x;             // n_seg + 1: the hit records of the depth above, whose shadow rays are traced at this depth
-    uint32_t* stage = pre_hits + F.n_seg + 1;
+    uint32_t* stage = scratch + blockDim.x;
     __shared__ uint32_t out_n, slow_n;
     if (threadIdx.x == 0) { out_n = 0; slow_n = 0; }
     SetupInput in;
-    in.pre = pre; in.pre_hits = pre_hits;
+    in.pre = pre; in.pre_hits = pre;
+    in.table = pre; in.table_scratch = scratch;
+    // (the hit records of the depth above, whose shadow rays are traced at this depth: only their number for now)
+    in.n_hits = build_prefix(L.hit_counts, F.n_seg, F.seg_hits, F.ovf_hits, pre, scratch);
     in.n_rays = build_prefix(L.ray_counts, F.n_seg, F.seg_rays, F.ovf_rays, pre, scratch);
-    in.n_hits = build_prefix(L.hit_counts, F.n_seg, F.seg_hits, F.ovf_hits, pre_hits, scratch);
     in.own_rays = in.own_hits = 0; in.extra_rays = in.extra_hits = nullptr;
     stage_analytic(S, stage);
     setup_rays<false>(S, F, level, in, stage, &out_n, &slow_n);
@@ -2330,6 +2344,7 @@ __global__ void __launch_bounds__(RT_SHADE_THREADS) rt_shade(const DScene S, con
         __syncthreads();
         SetupInput in;
         in.pre = in.pre_hits = nullptr;
+        in.table = in.table_scratch = nullptr;
         in.own_rays = out_rays < F.seg_rays ? out_rays : F.seg_rays;
         in.own_hits = out_hits < F.seg_hits ? out_hits : F.seg_hits;
         in.extra_rays = extra_rays; in.extra_hits = extra_hits;
@@ -2457,7 +2472,7 @@ extern "C" int rt_query_setup_blocks_per_cu(const DScene* S, uint32_t n_seg) {
     const size_t setup_words = analytic_stage_words(*S) + setup_work_words(S->range_depth, RT_SETUP_THREADS);
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, rt_setup, RT_SETUP_THREADS,
-                                                     list_lds_bytes(n_seg) + (n_seg + 1 + setup_words) * sizeof(uint32_t)) != hipSuccess)
+                                                     list_lds_bytes(n_seg) + setup_words * sizeof(uint32_t)) != hipSuccess)
         return -1;
     return n;
 }
@@ -2473,7 +2488,7 @@ extern "C" hipError_t rt_launch_level(const DScene* S, const DFrame* F, uint32_t
     const size_t setup_words = analytic_stage_words(*S) + setup_work_words(S->range_depth, RT_SETUP_THREADS);
     if (level == 0 || !F->fuse_setup)
         hipLaunchKernelGGL(rt_setup, dim3(setup_blocks < blocks ? setup_blocks : blocks), dim3(RT_SETUP_THREADS),
-                           lds + (F->n_seg + 1 + setup_words) * sizeof(uint32_t), stream, *S, *F, level);
+                           lds + setup_words * sizeof(uint32_t), stream, *S, *F, level);
     // In a scene whose instances all have culling boxes only stray rays (NaN components) reach this kernel, if any:
     // a small grid keeps the usual empty launch cheap.  (Block b continues list segment b, so any grid <= blocks works.)
     const uint32_t slow_blocks = (S->all_cullable && blocks > 64) ? 64 : blocks;
