@@ -545,7 +545,9 @@ extern "C" int rt_scene_create(const RtSceneDesc* desc, int device_id, RtScene**
     std::vector<float> range_limits;
     uint32_t range_depth = 0;
     {
-        bool usable = instances.size() > RT_RANGE_TREE_MIN;
+        size_t range_tree_min = RT_RANGE_TREE_MIN;
+        if (const char* env = getenv("RT_RANGE_TREE_MIN")) { const int v = atoi(env); if (v >= 0) range_tree_min = (size_t)v; }
+        bool usable = instances.size() > range_tree_min;
         for (const DInstance& di : instances) usable = usable && (di.cullable || di.root_ref == RT_REF_NONE);
         if (usable) {
             struct Build {

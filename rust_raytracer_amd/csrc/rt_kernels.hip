@@ -819,7 +819,7 @@ __device__ __forceinline__ void analytic_hits(const DScene& S, const DPlane* pla
 }
 
 // Words of LDS the analytic primitives take when staged (rt_setup), 0 when they are too many to stage.  Behind them, in
-// scenes whose instances are scanned one by one (no range tree: at most 16), a culling record of RT_CULL_WORDS words per
+// scenes whose instances are scanned one by one (no range tree: at most 16 by default, 64 at most), a culling record of RT_CULL_WORDS words per
 // instance: world_lo, world_hi, cull_origin_limit, bits root_ref.
 #define RT_STAGE_WORDS_MAX 4096
 #define RT_CULL_WORDS 8
@@ -829,7 +829,7 @@ __host__ __device__ inline uint32_t primitive_stage_words(const DScene& S) {
     return w <= RT_STAGE_WORDS_MAX ? (uint32_t)w : 0u;
 }
 __host__ __device__ inline uint32_t cull_stage_words(const DScene& S) {
-    return (primitive_stage_words(S) != 0 && S.n_range_nodes == 0 && S.n_instances <= 32) ? RT_CULL_WORDS * S.n_instances : 0u;
+    return (primitive_stage_words(S) != 0 && S.n_range_nodes == 0 && S.n_instances <= 64) ? RT_CULL_WORDS * S.n_instances : 0u;
 }
 __host__ __device__ inline uint32_t analytic_stage_words(const DScene& S) { return primitive_stage_words(S) + cull_stage_words(S); }
 
@@ -1098,7 +1098,7 @@ __device__ __forceinline__ void setup_rays(const DScene& S, const DFrame& F, con
         // nothing but broadcast reads and arithmetic (one bit per instance), and the pairs are pushed afterwards; as scalar
         // loads in the loop that also pushes, each instance cost a round trip to the scalar cache of its own - the four
         // boxes of the 1080p bunnies frame as much time as its seven analytic primitives.
-        uint32_t want_bits = 0;
+        unsigned long long want_bits = 0;
         if (cull_words && active && !settled) {
 #pragma unroll 4
             for (uint32_t ii = 0; ii < S.n_instances; ++ii) {
@@ -1108,13 +1108,13 @@ __device__ __forceinline__ void setup_rays(const DScene& S, const DFrame& F, con
                                (!(o_l1 < __uint_as_float(c[6])) ||
                                 (slab(__uint_as_float(c[0]), __uint_as_float(c[1]), __uint_as_float(c[2]), __uint_as_float(c[3]),
                                       __uint_as_float(c[4]), __uint_as_float(c[5]), r.o, inv_w, tmin_w) && !(tmin_w > lw_cut)));
-                want_bits |= (w ? 1u : 0u) << ii;
+                want_bits |= (w ? 1ull : 0ull) << ii;
             }
         }
         RT_SU_MARK(2)
         for (uint32_t ii = 0; ii < (S.n_range_nodes ? 0u : S.n_instances); ++ii) {
             if (cull_words) {
-                const bool want_item = (want_bits >> ii) & 1u;
+                const bool want_item = (want_bits >> ii) & 1ull;
                 if (!__ballot(want_item)) continue;
                 ring_push(R, want_item, r, lw, gi, ii, rr, ss, lane);
                 if (R.count >= RT_WAVE) ring_drain(R, S, F, L, &out_n, lane);
