@@ -556,6 +556,7 @@ def main():
         s.dev.close()
     if world > 1:
         dist.barrier()
+    if collective:
         dist.destroy_process_group()
 
 
