@@ -1276,8 +1276,15 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_setup_slow(const DScene S
                 lr.d = mk(dv.x / dn, dv.y / dn, dv.z / dn);                 // glm::normalize, intersect.rs:304-308
                 if (all_here) {
                     // reference order, to the end, right here
-                    bool m_have; float m_t, m_u, m_v; uint32_t m_slot;
-                    exact_mesh_hit(S, inst.root_ref, lr, m_have, m_t, m_u, m_v, m_slot);
+                    bool m_have = false; float m_t = 0.0f, m_u = 0.0f, m_v = 0.0f; uint32_t m_slot = 0;
+                    // The reference tests every node's own box, the root's included (intersect.rs:247-250).  The walk below
+                    // tests a node's children's boxes when it visits the node, so the root's box has to be tested here: a
+                    // mesh of a single leaf has no other box, and with NaN in the ray - or in a tree whose boxes do not
+                    // nest - a child's box can pass where the root's does not.
+                    float t_root;
+                    if (slab(inst.root_lo[0], inst.root_lo[1], inst.root_lo[2], inst.root_hi[0], inst.root_hi[1], inst.root_hi[2], lr.o,
+                             mk(1.0f / lr.d.x, 1.0f / lr.d.y, 1.0f / lr.d.z), t_root))
+                        exact_mesh_hit(S, inst.root_ref, lr, m_have, m_t, m_u, m_v, m_slot);
                     if (m_have) {
                         float tw = world_t(S, inst, lr, r.o, m_t, m_slot);
                         if (closer(have, best_t, tw)) {

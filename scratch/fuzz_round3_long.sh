@@ -1,0 +1,15 @@
+#!/bin/bash
+# On the GPU box: a longer run of two generators over fresh seeds -> gpurun_out/fuzz3_long_<part>.txt     bash scratch/fuzz_round3_long.sh a|b
+part=$1
+mkdir -p gpurun_out
+out=gpurun_out/fuzz3_long_$part.txt
+: > $out
+run() { echo "== scratch/$1" >> $out; timeout -k 10 $4 python scratch/$1 $2 $3 > gpurun_out/fuzz3_long_$1.log 2>&1; rc=$?; tail -1 gpurun_out/fuzz3_long_$1.log >> $out; echo "$1 rc=$rc"; [ $rc -eq 0 ] || exit 1; }
+case $part in
+  a) run fuzz_many.py 402000 407000 1100 ;;
+  d) run fuzz_many.py 407000 437000 1150 ;;
+  e) run fuzz_degenerate.py 95500 110500 1150 ;;
+  b) run fuzz_degenerate.py 91500 95500 1100 ;;
+  c) run fuzz_mixed.py 30500 32000 1100 ;;
+esac
+cat $out

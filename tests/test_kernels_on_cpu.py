@@ -111,9 +111,12 @@ def test_result_only_entries_are_not_walked(emu_render, tmp_path):
     have shallower trees than the scene's first mesh.  A walk that takes such an entry for a walk item walks the first
     mesh with a null ray that passes every box, on a stack sized for the meshes the scene instances: the sanitizer
     stops at the push.  (The reference's own walk panics in the same place when its 32 entries are exceeded,
-    intersect.rs:240-255.)  Neighbouring seeds of the generator ride along."""
+    intersect.rs:240-255.)  Neighbouring seeds of the generator ride along - and seed 30922: a mesh of one triangle, whose
+    root is a leaf, beside an instance with a singular matrix under an orthographic camera 5e7 units away.  Its rays take
+    the exact path, which has to test the root's own box as the reference does (intersect.rs:247-250): from that far the
+    box test fails where the triangle test passes."""
     d = str(tmp_path)
-    for seed in (9019, 9020, 9023):
+    for seed in (9019, 9020, 9023, 30922):
         work = tmp_path / ("mixed%d" % seed)
         work.mkdir()
         text, depth, what = synthetic.mixed_scene(d, seed)
