@@ -10,6 +10,9 @@ case $part in
   d) run fuzz_many.py 407000 437000 1150 ;;
   e) run fuzz_degenerate.py 95500 110500 1150 ;;
   b) run fuzz_degenerate.py 91500 95500 1100 ;;
-  c) run fuzz_mixed.py 30500 32000 1100 ;;
+  c) run fuzz_mixed.py 30500 36000 1150 ;;
+  f) run fuzz_extremes.py 9200 10700 380 && run fuzz_camera.py 9200 10700 380 && run fuzz_meshes.py 9200 10700 380 ;;
+  g) run fuzz_grid.py 6100 6900 500 && run fuzz_counts.py 8100 8500 300 && run fuzz_shards.py 9300 10800 380 ;;
+  h) run fuzz_depth_map.py 9200 10700 380 && run fuzz_refractive_meshes.py 9200 10000 500 ;;
 esac
 cat $out
