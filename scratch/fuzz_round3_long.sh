@@ -14,5 +14,7 @@ case $part in
   f) run fuzz_extremes.py 9200 10700 380 && run fuzz_camera.py 9200 10700 380 && run fuzz_meshes.py 9200 10700 380 ;;
   g) run fuzz_grid.py 6100 6900 500 && run fuzz_counts.py 8100 8500 300 && run fuzz_shards.py 9300 10800 380 ;;
   h) run fuzz_depth_map.py 9200 10700 380 && run fuzz_refractive_meshes.py 9200 10000 500 ;;
+  i) run fuzz_odd_materials.py 1000 4000 560 && run fuzz_far_camera.py 1000 3000 560 ;;
+  j) run fuzz_far_camera.py 3000 5000 1100 ;;
 esac
 cat $out
