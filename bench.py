@@ -529,6 +529,8 @@ def main():
                        # rays are counted as the reference traces them; of the shadow rays, these were settled without a trace
                        # because their verdict cannot change the picture (RT_CTR_SHADOW_NOT_TRACED in include/rt_hip.h)
                        "shadow_not_traced": int(rays[12]),
+                       "rays_counted": "the rays the reference traces for these frames (checked against the oracle's count); the shadow rays in "
+                                       "shadow_not_traced are among them - settled without a trace because their verdict cannot change the picture",
                        "frames_in_flight": depth * views, "passes_in_flight": depth, "views_per_pass": views,
                        "list_bytes_per_pass": list_use["bytes"], "list_bytes_per_view": list_use["bytes"] // max(views, 1),
                        "parallelism": ("tile-sharded x%d, scene replicated, %s" % (world, "REHEARSAL: ranks share one GPU, gloo"

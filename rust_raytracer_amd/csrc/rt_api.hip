@@ -840,6 +840,7 @@ static int ensure_frame(RtScene* s, const Geometry& g, uint32_t max_depth, bool 
         want.fat = half_again(s->seen_per_pixel[1]);
         want.hits = half_again(s->seen_per_pixel[2]);
     } else {
+        while (want.rays > limit && want.rays > g.n_pixels) want = caps_from_rays(want.rays / 2);      // (passes of a quarter of 2^30 pixels and more)
         size_t free_bytes = 0, total_bytes = 0;
         if (hipMemGetInfo(&free_bytes, &total_bytes) == hipSuccess) {
             const size_t room = (free_bytes + s->frame_bytes) / 10 * 8;
