@@ -16,5 +16,7 @@ case $part in
   h) run fuzz_depth_map.py 9200 10700 380 && run fuzz_refractive_meshes.py 9200 10000 500 ;;
   i) run fuzz_odd_materials.py 1000 4000 560 && run fuzz_far_camera.py 1000 3000 560 ;;
   j) run fuzz_far_camera.py 3000 5000 1100 ;;
+  k) run fuzz_mixed.py 36200 42000 1150 ;;
+  l) run fuzz_mixed.py 42000 48000 1150 ;;
 esac
 cat $out
