@@ -125,7 +125,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=96)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--repeats", type=int, default=7, help="times the timed region of --steps frames is run; the median is reported")
+    ap.add_argument("--repeats", type=int, default=15, help="times the timed region of --steps frames is run; the median is reported")
     ap.add_argument("--workload", default="reflective_bunnies_1080p", choices=sorted(WORKLOADS))
     ap.add_argument("--model-dir", default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
