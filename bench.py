@@ -123,7 +123,9 @@ def cpu_baseline(scene_path, model_dir, width, height, max_depth, budget_s=15.0)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=96)
+    ap.add_argument("--steps", type=int, default=0,
+                    help="frames in the timed region; default 96 per rank up to four ranks (96, 192, 384, 384 for 1, 2, 4, 8 ranks): three passes of "
+                         "as many views as make 32 whole frames' worth of pixels per rank")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--repeats", type=int, default=15, help="times the timed region of --steps frames is run; the median is reported")
     ap.add_argument("--workload", default="reflective_bunnies_1080p", choices=sorted(WORKLOADS))
@@ -157,6 +159,9 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.steps <= 0:
+        # (a rehearsal's ranks share one GPU's memory: it keeps to 96)
+        args.steps = 96 if args.rehearse_on_one_gpu else 96 * min(max(world, 1), 4)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
@@ -230,7 +235,7 @@ def main():
             cameras.append(cameras[0])
             continue
         host.set_camera_pose(position0, orientation0)
-        step = 12.0 * ((k + 1) // 2)
+        step = 12.0 * ((k % 96 + 1) // 2)             # (from the 97th frame on the cameras repeat)
         host.turn_camera(0.0, 0.0, step if k % 2 else -step, 0.0)
         cameras.append(np.asarray(host.camera()[0], dtype=np.float32).reshape(16))
     host.set_camera_pose(position0, orientation0)
@@ -390,8 +395,8 @@ def main():
                 checked += 1
     one.dev.set_views(cameras[0].reshape(1, 16), w, h)
     if not args.same_camera and n_cameras > 1:
-        assert len({s.frames()[v].cpu().numpy().tobytes() for s in every_slot for v in range(s.views)}) == n_cameras, \
-            "two cameras of the timed region gave the same frame"
+        assert len({s.frames()[v].cpu().numpy().tobytes() for s in every_slot for v in range(s.views)}) == min(n_cameras, 96), \
+            "two different cameras of the timed region gave the same frame"
 
     # Per-kernel durations, live: the same steps once more with every launch of the per-depth
     # kernels bracketed by HIP events on the launch stream (outside the timed region above, so that
@@ -522,7 +527,7 @@ def main():
                                if n_tris else "none",
                        "cameras": "every frame of the scene's own camera" if args.same_camera else
                                   "%d distinct cameras: the scene's own and %d drags of it (12 pixels apart, both ways); %d of the "
-                                  "frames compared byte for byte with the same camera rendered alone" % (n_cameras, n_cameras - 1, checked),
+                                  "frames compared byte for byte with the same camera rendered alone" % (min(n_cameras, 96), min(n_cameras, 96) - 1, checked),
                        "rays_in_timed_region": int(region_rays[0]), "mean_rays_per_frame": int(region_rays[0]) / max(args.steps, 1),
                        "rays_per_frame": rays_per_frame, "primary": int(frame_rays[1]), "shadow": int(frame_rays[2]),
                        "reflected": int(frame_rays[3]), "transmitted": int(frame_rays[4]),

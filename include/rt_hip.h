@@ -248,7 +248,7 @@ int rt_scene_set_camera(RtScene* scene, const float screen_to_world[16], uint32_
  * (a last, smaller pass of a batch) allocates nothing.
  * The reference has no counterpart: its renderers draw one camera per call (gpu_renderer.rs:280, main.rs:46-66);
  * a caller with a queue of frames (an animation, the batch of orbit views) would loop over it. */
-#define RT_MAX_VIEWS 32
+#define RT_MAX_VIEWS 256     /* and n_views * (pixels of a view, or of a shard of it) <= 2^28 */
 int rt_scene_set_views(RtScene* scene, const float* screen_to_world, uint32_t n_views, uint32_t width, uint32_t height);
 
 /* Replaces paint_scene (native_app/src/main.rs:46-66) and GpuRenderer::render (gpu_renderer.rs:280-354):

@@ -33,7 +33,7 @@ COUNTER_NAMES = ["rays", "primary", "shadow", "reflected", "transmitted", "aabb_
 LIST_USE_NAMES = ["bytes", "ray_slots", "walk_slots", "hit_slots", "rays", "walk_items", "hits"]
 RT_FORMAT_RGB8, RT_FORMAT_RGBA8 = 0, 1
 RT_TILE_DIM = 32
-RT_MAX_VIEWS = 32
+RT_MAX_VIEWS = 256
 
 f32, u32, i32 = C.c_float, C.c_uint32, C.c_int32
 

@@ -17,7 +17,7 @@
 #include "rt_device.h"
 
 extern "C" {
-hipError_t rt_launch_generate(const DFrame* F, const DViews* V, uint32_t blocks, hipStream_t stream);
+hipError_t rt_launch_generate(const DFrame* F, const float* matrices, uint32_t blocks, hipStream_t stream);
 int rt_query_setup_blocks_per_cu(const DScene* S, uint32_t n_seg);
 hipError_t rt_launch_level(const DScene* S, const DFrame* F, uint32_t level, uint32_t last, uint32_t blocks, uint32_t setup_blocks, uint32_t traverse_blocks,
                            hipStream_t stream, hipEvent_t* marks);      // launches rt_setup_slow iff F->slow_launched
@@ -97,7 +97,7 @@ struct RtScene {
     std::vector<void*> scene_allocs;
     DScene d{};
     bool camera_set = false;
-    DViews views{};                     // screen_to_world of every view
+    std::vector<float> views = std::vector<float>(16, 0.0f);      // screen_to_world of every view, 16 floats each
     uint32_t n_views = 1;
     uint32_t width = 0, height = 0;
     // per-frame buffers, reallocated when the key below changes
@@ -671,7 +671,7 @@ extern "C" int rt_scene_set_views(RtScene* s, const float* screen_to_world, uint
     if (width == 0 || height == 0) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_set_views: empty screen %ux%u", width, height);
     if (n_views == 0 || n_views > RT_MAX_VIEWS)
         return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_set_views: %u views; between 1 and %d are supported", n_views, RT_MAX_VIEWS);
-    memcpy(s->views.m, screen_to_world, (size_t)n_views * 64);
+    s->views.assign(screen_to_world, screen_to_world + (size_t)n_views * 16);
     s->n_views = n_views;
     s->width = width;
     s->height = height;
@@ -1017,7 +1017,7 @@ static int enqueue_frame(RtScene* s, const RtRenderParams* p, bool sharded, bool
     if (noalloc) HIP_TRY(hipMemsetAsync(f.acc_big, 0, (size_t)3 * g.n_pixels * sizeof(double), stream));
     if (aux) HIP_TRY(hipMemsetAsync(f.aux_flags, 0, (size_t)g.n_pixels * sizeof(unsigned int), stream));
     HIP_TRY(hipEventRecord(s->ev_trace_start, stream));
-    HIP_TRY(rt_launch_generate(&f, &s->views, blocks, stream));
+    HIP_TRY(rt_launch_generate(&f, s->views.data(), blocks, stream));
     s->marked_levels = 0;
     if (s->kernel_timing && !noalloc) {
         while (s->marks.size() < (RT_N_LEVEL_KERNELS + 1) * (size_t)(last + 1)) {

@@ -147,7 +147,9 @@ struct DScene {
 #define RT_MOOT_SPECULAR_FINITE 8u    // ... is finite in every channel and shininess > 0
 
 // The cameras of the views of a frame (rt_generate's own argument): column-major screen_to_world matrices.
-struct DViews { float m[RT_MAX_VIEWS][16]; };
+// (as many as one launch of rt_generate takes as its argument; a pass of more views is generated by several launches)
+#define RT_VIEWS_PER_LAUNCH 32
+struct DViews { float m[RT_VIEWS_PER_LAUNCH][16]; };
 
 // Rows of DFrame::counts at depth d.
 #define RT_ROW_RAYS 0    // the rays traced at depth d (written by rt_generate, or by rt_shade at depth d - 1)

@@ -838,22 +838,25 @@ __host__ __device__ inline uint32_t analytic_stage_words(const DScene& S) { retu
 // ======================================================================================================
 // Kernel 0: primary rays (raytracer.rs:30-51) for this shard's pixels -> ray list of depth 0.
 // ======================================================================================================
-__global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_generate(const DFrame F, const DViews V) {
+// One launch generates the rays of the `n_here` local pixels from `first_pixel` on - the pixels of up to RT_VIEWS_PER_LAUNCH
+// views, whose matrices V holds; a pass of more views takes several launches, and a block's list segment goes on where
+// the launch before left it.
+__global__ void __launch_bounds__(RT_BLOCK_THREADS) rt_generate(const DFrame F, const DViews V, const uint32_t first_pixel, const uint32_t n_here) {
     __shared__ uint32_t out_n;
-    if (threadIdx.x == 0) out_n = 0;
+    if (threadIdx.x == 0) out_n = F.counts[RT_ROW_RAYS * F.n_seg + blockIdx.x];       // (cleared when the frame starts)
     __syncthreads();
     const uint32_t lane = threadIdx.x & (RT_WAVE - 1);
     const uint32_t gwave = (blockIdx.x * blockDim.x + threadIdx.x) / RT_WAVE;
     const uint32_t n_waves = gridDim.x * (blockDim.x / RT_WAVE);
-    for (uint32_t c = gwave; (unsigned long long)c * RT_WAVE < F.n_pixels; c += n_waves) {
-        const uint32_t p = c * RT_WAVE + lane;
+    for (uint32_t c = gwave; (unsigned long long)c * RT_WAVE < n_here; c += n_waves) {
+        const uint32_t p = first_pixel + c * RT_WAVE + lane;
         uint32_t view = 0, col = 0, row = 0;
-        const bool inside = p < F.n_pixels && pixel_coords(F, p, view, col, row);
+        const bool inside = c * RT_WAVE + lane < n_here && pixel_coords(F, p, view, col, row);
         RayRec rr;
         rr.ray.o = rr.ray.d = mk(0, 0, 0);
         // a wave's 64 pixels lie in one view (view_pixels is a multiple of 64): the matrix index is wave-uniform
-        const uint32_t wave_view = __builtin_amdgcn_readfirstlane(c * RT_WAVE / F.view_pixels);
-        if (inside) rr.ray = primary_ray(F, V.m[wave_view < F.n_views ? wave_view : 0], col, row);
+        const uint32_t wave_view = __builtin_amdgcn_readfirstlane(c * RT_WAVE / F.view_pixels);      // among this launch's views
+        if (inside) rr.ray = primary_ray(F, V.m[wave_view < RT_VIEWS_PER_LAUNCH ? wave_view : 0], col, row);
         rr.throughput = 1.0f;
         rr.meta = p;
         uint32_t slot = append_slot(inside, &out_n, F.seg_rays, F.n_seg, F.counts + RT_ROW_RAYS * F.n_seg, F.ovf_rays, F.overflow, F.overflow_seq, lane);
@@ -2463,8 +2466,15 @@ extern "C" int rt_query_traverse_blocks_per_cu(uint32_t n_seg, uint32_t stack_en
     return n;
 }
 
-extern "C" hipError_t rt_launch_generate(const DFrame* F, const DViews* V, uint32_t blocks, hipStream_t stream) {
-    hipLaunchKernelGGL(rt_generate, dim3(blocks), dim3(RT_BLOCK_THREADS), 0, stream, *F, *V);
+// `matrices`: F->n_views column-major screen_to_world matrices in host memory (copied into the launches' arguments).
+extern "C" hipError_t rt_launch_generate(const DFrame* F, const float* matrices, uint32_t blocks, hipStream_t stream) {
+    for (uint32_t first = 0; first < F->n_views; first += RT_VIEWS_PER_LAUNCH) {
+        const uint32_t n = F->n_views - first < RT_VIEWS_PER_LAUNCH ? F->n_views - first : RT_VIEWS_PER_LAUNCH;
+        DViews V;
+        for (uint32_t k = 0; k < RT_VIEWS_PER_LAUNCH; ++k)                    // (the unused ones repeat the first)
+            for (uint32_t i = 0; i < 16; ++i) V.m[k][i] = matrices[(size_t)16 * (first + (k < n ? k : 0)) + i];
+        hipLaunchKernelGGL(rt_generate, dim3(blocks), dim3(RT_BLOCK_THREADS), 0, stream, *F, V, first * F->view_pixels, n * F->view_pixels);
+    }
     return hipGetLastError();
 }
 

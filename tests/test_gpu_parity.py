@@ -540,6 +540,50 @@ def test_lists_are_sized_by_what_the_handle_has_seen(scenes_dir, model_dir):
         dev.close()
 
 
+def test_a_hundred_views_in_one_pass(scenes_dir, model_dir):
+    """A pass takes up to RT_MAX_VIEWS = 256 views; rt_generate takes 32 at a time, so a pass of 100 is four launches that
+    fill the same list segments one after the other.  Every view's bytes equal the frame rendered alone, the pass's ray counts
+    their sum - whole frames and as one of three tile shards."""
+    import torch
+    from rust_raytracer_amd import synthetic
+    w, h, n = 320, 180, 100
+    host = native.HostScene.load(os.path.join(scenes_dir, "reflective_bunnies.json"), model_dir)
+    host.resize_screen(w, h)
+    mats = []
+    for position, orientation in synthetic.orbit_poses(n, centre=(0.0, 0.0, -6.0)):
+        host.set_camera_pose(position, orientation)
+        mats.append(np.asarray(host.camera()[0], dtype=np.float32).reshape(16))
+    dev = native.DeviceScene(host.desc(), 0)
+    single = native.DeviceScene(host.desc(), 0)
+    try:
+        def render(d, buf, **kw):
+            for attempt in range(5):
+                d.render_device(buf.data_ptr(), **kw)
+                try:
+                    return d.last_ray_counts()
+                except native.RtError:
+                    if attempt == 4:
+                        raise
+        for shard_count in (1, 3):
+            kw = {} if shard_count == 1 else {"shard_index": 1, "shard_count": 3}
+            dev.set_views(np.stack(mats), w, h)
+            per_view = dev.shard_bytes(shard_count=shard_count) if shard_count > 1 else h * w * 3
+            together = torch.zeros(n * per_view, dtype=torch.uint8, device="cuda")
+            alone = torch.zeros(per_view, dtype=torch.uint8, device="cuda")
+            total = render(dev, together, **kw)
+            got = together.cpu().numpy().reshape(n, per_view)
+            rays = np.zeros(5, dtype=np.int64)
+            for v in range(n):
+                single.set_camera(mats[v], w, h)
+                rays += render(single, alone, **kw)[:5].astype(np.int64)
+                assert np.array_equal(got[v], alone.cpu().numpy()), (shard_count, v)
+            assert total[:5].astype(np.int64).tolist() == rays.tolist()
+    finally:
+        dev.close()
+        single.close()
+        host.close()
+
+
 def test_five_4k_views_in_one_pass(scenes_dir, model_dir):
     """Five 3840x2160 views are 41 M pixels in one pass - more than the 2^25 a ray's pixel field once held (now 2^28).  Every
     view's bytes equal the frame rendered on its own."""

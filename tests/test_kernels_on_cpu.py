@@ -179,14 +179,14 @@ def test_tree_whose_boxes_do_not_nest(emu_render, scenes_dir, model_dir, tmp_pat
 
 def test_other_entry_points(emu_render, scenes_dir, model_dir, tmp_path):
     """The same picture through the other ways into the kernels: three tile shards put together by rt_assemble_shards, two
-    views in one pass, the allocation-free entry point - byte for byte the plain render - and the depth-map mode (run for
-    the sanitizer's sake)."""
+    views in one pass, 34 views in one pass (more than one launch of rt_generate takes), the allocation-free entry point -
+    byte for byte the plain render - and the depth-map mode (run for the sanitizer's sake)."""
     text = small(scenes_dir, "reflective_bunnies", 72, 40)
     path = str(tmp_path / "scene.json")
     with open(path, "w") as f:
         f.write(text)
     outputs = {}
-    for mode in ("plain", "shards:3", "views:2", "noalloc", "depthmap"):
+    for mode in ("plain", "shards:3", "views:2", "views:34", "noalloc", "depthmap"):
         env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
         if mode != "plain":
             env["EMU_MODE"] = mode
@@ -194,7 +194,7 @@ def test_other_entry_points(emu_render, scenes_dir, model_dir, tmp_path):
         r = subprocess.run([emu_render, model_dir, "4", path, out], capture_output=True, text=True, env=env)
         assert r.returncode == 0, (mode, r.stderr[-4000:])
         outputs[mode] = np.fromfile(out + ".rgb", dtype=np.uint8)
-    for mode in ("shards:3", "views:2", "noalloc"):
+    for mode in ("shards:3", "views:2", "views:34", "noalloc"):
         assert np.array_equal(outputs[mode], outputs["plain"]), mode
     assert outputs["depthmap"].any() and not np.array_equal(outputs["depthmap"], outputs["plain"])
 
