@@ -18,5 +18,8 @@ case $part in
   j) run fuzz_far_camera.py 3000 5000 1100 ;;
   k) run fuzz_mixed.py 36200 42000 1150 ;;
   l) run fuzz_mixed.py 42000 48000 1150 ;;
+  m) run fuzz_mixed.py 48000 54000 1150 ;;
+  n) run fuzz_odd_materials.py 4000 10000 1150 ;;
+  o) run fuzz_far_camera.py 6000 10000 1150 ;;
 esac
 cat $out
